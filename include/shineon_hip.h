@@ -1,0 +1,215 @@
+/* C ABI of libshineon_hip.so — the MI355X (gfx950) kernels behind the ShineOn try-on hot path.
+ *
+ * The reference (andrewjong/ShineOn-Virtual-Tryon) has no FFI of its own: its hot path calls PyTorch
+ * ops from Python.  Each entry point below therefore names the reference call site (file:line under the
+ * reference tree) whose torch op it replaces; INTEGRATION.md shows the ctypes stub a maintainer would
+ * add.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; nothing is allocated,
+ *     freed or synchronised inside the library; `stream` is a hipStream_t (NULL = default stream);
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative SO_ERR_* code;
+ *   - activations are "rows x channels" NHWC matrices: element (pixel p, channel c) lives at
+ *     ptr[p * ld + c]; `ld` (floats) may exceed the channel count so that a channel slice of a wider
+ *     buffer (a U-Net skip concatenation) is a valid operand;
+ *   - convolution weights are OHWI: w[ko][r][s][c] (a torch (O,I,H,W) tensor in channels_last memory
+ *     format), gradients are produced in the same layout;
+ *   - `ws`/`ws_bytes` is caller-owned scratch; the so_*_ws_floats helpers give the required size.
+ */
+#ifndef SHINEON_HIP_H_
+#define SHINEON_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO_ERR_ALIGN (-1) /* pointer not 16-byte aligned / channel count or stride not a multiple of 4 */
+#define SO_ERR_SHAPE (-2) /* unsupported shape combination */
+
+/* activation codes (models/networks/cpvton/unet.py:132-135,201-211; models/networks/activation.py) */
+#define SO_ACT_NONE_ 0
+#define SO_ACT_RELU_ 1
+#define SO_ACT_LEAKY_ 2
+#define SO_ACT_GELU_ 3
+#define SO_ACT_SWISH_ 4
+#define SO_ACT_SINE_ 5
+#define SO_ACT_TANH_ 6
+#define SO_ACT_SIGMOID_ 7
+
+/* ---- convolution / matmul on fp32 MFMA (csrc/igemm.hip) ------------------------------------------ */
+
+/* nn.Conv2d forward (unet.py:129-131,139-174; warp.py:13-31,73-85; sagan.py:12-20; vgg.py:9-23):
+ * y = act(conv(x, w) + bias).  x: [Nb*H*W][C] (ldx), y: [Nb*Ho*Wo][Ko] (ldy), C % 4 == 0. */
+int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
+                    float act_param, float* ws, long long ws_bytes, void* stream);
+
+/* input gradient of the same convolution (autograd of the call sites above): dx: [Nb*H*W][C]. */
+int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nb, int H,
+                    int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                    long long ws_bytes, void* stream);
+
+/* weight gradient: dw[ko][r][s][c] (OHWI, dense). */
+int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,
+                    int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                    long long ws_bytes, void* stream);
+
+/* torch.bmm replacement (sagan.py:44,50; warp.py:63):
+ * C[b] = act(alpha[0] * opA(A[b]) opB(B[b]) + bias[n] + res[b]),  alpha/bias/res optional (NULL).
+ * transa 0: A [M][K]; 1: A [K][M].  transb 0: B [K][N]; 1: B [N][K].  (transa=1,transb=1 unsupported) */
+int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A, int lda,
+                    long long sa, const float* B, int ldb, long long sb, float* C, int ldc,
+                    long long sc, int batch, const float* alpha, const float* bias,
+                    const float* res, int ldres, long long sres, int act, float act_param,
+                    float* ws, long long ws_bytes, void* stream);
+
+/* test hook: force the block tile (128 / 64, 0 = auto) and split-K factor (0 = auto). */
+void so_igemm_force(int bm, int splitk);
+
+/* ---- normalisation (csrc/norm.hip) ---------------------------------------------------------------- */
+
+/* floats of scratch needed by so_norm_fwd / so_norm_bwd */
+long long so_norm_ws_floats(int G, long long R, int C);
+
+/* InstanceNorm2d (G = batch, R = H*W; unet.py:136,146) / BatchNorm2d training (G = 1, R = N*H*W;
+ * warp.py:15,21,29,75-84): y = (x - mean) * rstd [* gamma + beta]; mean/rstd [G][C] are outputs kept for
+ * backward; running_mean/var (optional) get the momentum update with the unbiased variance. */
+int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
+                const float* gamma, const float* beta, float* mean, float* rstd,
+                float* running_mean, float* running_var, float momentum, float* ws, void* stream);
+
+/* BatchNorm2d in eval mode (test_step): statistics are inputs; stat_is_var = 1 -> `stat` is a variance. */
+int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R, int C,
+                  const float* mean, const float* stat, int stat_is_var, float eps,
+                  const float* gamma, const float* beta, void* stream);
+
+int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* ---- pointwise / resampling / reductions (csrc/elementwise.hip) ---------------------------------- */
+
+/* LeakyReLU / ReLU / GELU / Swish / Sine / tanh / sigmoid (unet.py:132-135,201-211) */
+int so_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act,
+               float param, void* stream);
+int so_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
+               long long rows, int C, int act, float param, void* stream);
+
+/* torch.cat(dim=1) / channel slicing / zero channel padding (unet.py:198; unet_mask_model.py:69):
+ * dst[row][0:Cd] = src[row][0:Cs] (zero beyond Cs); accumulate != 0: dst += src. */
+int so_copy2d(const float* src, int lds_, int Cs, float* dst, int ldd, int Cd, long long rows,
+              int accumulate, void* stream);
+
+/* boundary layout changes: planar NCHW (the reference's batch tensors) <-> NHWC rows */
+int so_nchw_to_nhwc(const float* src, float* dst, int ldd, int Nb, int C, int Cd, int HW,
+                    void* stream); /* channels C..Cd-1 of dst are zero-filled */
+int so_nhwc_to_nchw(const float* src, int lds_, float* dst, int Nb, int C, int HW, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="bilinear") (unet.py:138,155,166), align_corners=False */
+int so_upsample2x_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
+                      void* stream);
+int so_upsample2x_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int H, int W, int C,
+                      void* stream);
+
+/* MaxPool2d(2, 2) of VGG19 (vgg.py:9-23) */
+int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
+                    void* stream);
+int so_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb,
+                    int H, int W, int C, void* stream);
+
+/* bias gradient: out[c] (+)= sum_rows x[row][c] */
+long long so_colsum_ws_floats(long long rows, int C);
+int so_colsum(const float* x, int ldx, long long rows, int C, float* out, int accumulate, float* ws,
+              void* stream);
+
+/* F.l1_loss / nn.L1Loss (warp_model.py:88; unet_mask_model.py:174-184; loss.py:110,121):
+ * out[0] (+)= scale * sum |a - b| (scale = weight / numel); ws >= 1024 floats.
+ * backward: da (+)= sign(a - b) * gout[0] * scale. */
+int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long rows, int C,
+                   float scale, float* out, int accumulate, float* ws, void* stream);
+int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
+                   float* da, int ldda, long long rows, int C, int accumulate, void* stream);
+
+/* tanh / sigmoid / mask blend of UnetMaskModel.forward (unet_mask_model.py:84-86,126-129), one frame:
+ * o: [pix][>=4] network output; cloth: [pix][>=3]; outputs rendered [pix][3], mask [pix][1],
+ * tryon [pix][tryon_pad] (channels >= 3 zero-filled so it can feed the VGG conv directly). */
+int so_tryon_compose_fwd(const float* o, int ldo, const float* cloth, int ldc, float* rendered,
+                         int ldr, float* mask, int ldm, float* tryon, int ldt, int tryon_pad,
+                         long long pix, void* stream);
+int so_tryon_compose_bwd(const float* rendered, int ldr, const float* mask, int ldm,
+                         const float* cloth, int ldc, const float* d_tryon, int lddt,
+                         const float* d_rendered, int lddr, const float* d_mask, int lddm, float* d_o,
+                         int lddo, long long pix, void* stream);
+
+/* torch.optim.Adam step on a flat parameter slab (base_model.py:165-168); g is scaled by grad_scale. */
+int so_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1,
+                 float b2, float eps, int step, float grad_scale, void* stream);
+
+/* out = alpha[0] * a + b with a device-resident alpha (SelfAttention: gamma * out + x, sagan.py:53) */
+int so_scale_add(const float* a, int lda, const float* alpha, const float* b, int ldb, float* out,
+                 int ldo, long long rows, int C, void* stream);
+
+/* out = (1 - m) * a + m * b, m a one-channel mask (multi-frame blends, unet_mask_model.py:118-129);
+ * backward: da, db, dm are optional (NULL to skip). */
+int so_blend_fwd(const float* a, int lda, const float* b, int ldb, const float* m, int ldm, float* out,
+                 int ldo, long long rows, int C, void* stream);
+int so_blend_bwd(const float* a, int lda, const float* b, int ldb, const float* m, int ldm,
+                 const float* g, int ldg, float* da, int ldda, float* db, int lddb, float* dm, int lddm,
+                 long long rows, int C, void* stream);
+
+int so_fill(float* p, long long n, float val, void* stream);
+int so_axpby(const float* x, float a, float* y, float b, long long n, void* stream);
+
+/* ---- geometric matching + attention row kernels (csrc/gmm.hip) ------------------------------------ */
+
+/* FeatureL2Norm (warp.py:39-50); inv[pix] = 1/sqrt(sum_c x^2 + 1e-6) kept for backward;
+ * transpose_hw writes pixel (h, w) to row w*H + h (FeatureCorrelation's transpose of A, warp.py:60). */
+int so_l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* inv, int Nb, int H, int W, int C,
+                  int transpose_hw, void* stream);
+int so_l2norm_bwd(const float* y, int ldy, const float* dy, int lddy, const float* inv, float* dx,
+                  int lddx, int Nb, int H, int W, int C, int transpose_hw, void* stream);
+
+/* nn.Softmax(dim=-1) on the attention energies (sagan.py:45) */
+int so_softmax_rows_fwd(const float* e, int lde, float* a, int lda, long long rows, int ncol,
+                        void* stream);
+int so_softmax_rows_bwd(const float* a, int lda, const float* da, int ldda, float* de, int ldde,
+                        long long rows, int ncol, void* stream);
+
+/* out[0] = scale * sum a*b (gradient of the attention gamma, sagan.py:53); ws >= 1024 floats */
+int so_dot(const float* a, int lda, const float* b, int ldb, long long rows, int C, float scale,
+           float* out, float* ws, void* stream);
+
+/* FeatureRegression.linear + tanh (warp.py:87,96-98): x NHWC [Nb][P][C] flattened in the reference's
+ * (C, H, W) order, w [J][C*P], y [Nb][J]. */
+int so_linear_chw_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int Nb,
+                      int P, int C, int J, int apply_tanh, void* stream);
+int so_linear_chw_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy,
+                      float* dx, int lddx, float* dw, float* dbias, int Nb, int P, int C, int J,
+                      int apply_tanh, void* stream);
+
+/* TpsGridGen.forward (warp.py:159-167,191-318): theta [Nb][2*NP] -> grid [Nb][H][W][2] (x, y).
+ * Li [(NP+3)^2] inverse TPS system, px/py [NP] control points, gx [W] / gy [H] the regular grid. */
+long long so_tps_ws_floats(int Nb, int H, int W, int NP);
+int so_tps_grid_fwd(const float* theta, const float* Li, const float* px, const float* py,
+                    const float* gx, const float* gy, float* grid, int Nb, int H, int W, int NP,
+                    float* ws, void* stream);
+int so_tps_grid_bwd(const float* dgrid, const float* Li, const float* px, const float* py,
+                    const float* gx, const float* gy, float* dtheta, int Nb, int H, int W, int NP,
+                    float* ws, void* stream);
+
+/* F.grid_sample(bilinear, align_corners=False; border = 1 -> padding_mode="border", 0 -> "zeros")
+ * (warp_model.py:85-86,143-145).  in [Nb][C][H][W] planar, grid [Nb][Ho][Wo][2], out [Nb][C][Ho][Wo];
+ * taps (optional int32 [Nb][Ho][Wo][2]) receives the north-west tap (x0, y0) of every output pixel. */
+int so_grid_sample_fwd(const float* in, const float* grid, float* out, int* taps, int Nb, int C, int H,
+                       int W, int Ho, int Wo, int border, void* stream);
+int so_grid_sample_bwd(const float* in, const float* grid, const float* dout, float* dgrid, float* din,
+                       int Nb, int C, int H, int W, int Ho, int Wo, int border, void* stream);
+
+/* Resample2d of the flownet2 submodule (unet_mask_model.py:115-117): out = bilinear(in, pixel + flow) */
+int so_resample2d_fwd(const float* in, const float* flow, float* out, int Nb, int C, int H, int W,
+                      void* stream);
+int so_resample2d_bwd(const float* in, const float* flow, const float* dout, float* din, float* dflow,
+                      int Nb, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHINEON_HIP_H_ */

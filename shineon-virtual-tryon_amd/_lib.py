@@ -1,0 +1,86 @@
+"""ctypes binding of libshineon_hip.so (the C ABI declared in include/shineon_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a kernel launch fails, the
+call raises.  `prototypes()` is also what the CPU test-suite uses to check that every symbol the
+header declares is exported.
+"""
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libshineon_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "shineon_hip.h")
+
+_lock = threading.Lock()
+_lib = None
+
+_CTYPES = {
+    "const float*": ctypes.c_void_p,
+    "float*": ctypes.c_void_p,
+    "int*": ctypes.c_void_p,
+    "void*": ctypes.c_void_p,
+    "int": ctypes.c_int,
+    "long long": ctypes.c_longlong,
+    "float": ctypes.c_float,
+    "void": None,
+}
+
+
+def prototypes(header_path=HEADER_PATH):
+    """Parse the C header -> {name: (restype, [argtypes])}."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long long|void)\s+(so_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = []
+        for a in [s.strip() for s in args.split(",") if s.strip()]:
+            a = re.sub(r"\s+", " ", a)
+            if a == "void":
+                continue
+            mm = re.match(r"(const float\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
+            if not mm:
+                raise RuntimeError(f"cannot parse argument '{a}' of {name}")
+            argtypes.append(_CTYPES[mm.group(1)])
+        protos[name] = (_CTYPES[ret], argtypes)
+    return protos
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library with argtypes set.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C shineon-virtual-tryon_amd/csrc`). There is no CPU fallback."
+            )
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in prototypes().items():
+            fn = getattr(cdll, name)  # AttributeError if the header declares something not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = cdll
+        return _lib
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+_ERRS = {-1: "SO_ERR_ALIGN (pointer/stride/channel alignment)", -2: "SO_ERR_SHAPE (unsupported shape)"}
+
+
+def check(err, what=""):
+    if err != 0:
+        raise HipKernelError(f"{what}: libshineon_hip returned {err} {_ERRS.get(err, '(hipError_t)')}")

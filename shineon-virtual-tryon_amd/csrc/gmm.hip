@@ -1,0 +1,639 @@
+// Geometric-matching (GMM / WarpModel) kernels and the small row-wise kernels of the SAGAN attention.
+//
+// Reference ops restated (file:line in /root/reference):
+//   FeatureL2Norm            models/networks/cpvton/warp.py:39-50   f / sqrt(sum_c f^2 + 1e-6)
+//   FeatureCorrelation       models/networks/cpvton/warp.py:53-67   (A transposed h<->w; the matmul itself is
+//                            so_gemm_batched in igemm.hip, this file supplies the transposed write of A)
+//   FeatureRegression.linear + tanh   models/networks/cpvton/warp.py:87,94-99 (flatten order is C,H,W)
+//   TpsGridGen.apply_transformation    models/networks/cpvton/warp.py:191-318
+//   F.grid_sample (bilinear, align_corners=False, padding border|zeros)   models/warp_model.py:85-86,143-145
+//   Resample2d (flownet2 submodule, absent from the reference tree)       models/unet_mask_model.py:115-117
+//   nn.Softmax(dim=-1) of the attention energies                          models/networks/attention/sagan.py:27,45
+#include "common.h"
+#include "../../include/shineon_hip.h"
+
+namespace {
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ FeatureL2Norm
+// One wavefront per pixel row.  transpose_hw: the output row of pixel (h, w) is w*H + h (the
+// `.transpose(2,3).contiguous()` that FeatureCorrelation applies to feature A).
+__global__ __launch_bounds__(256) void l2norm_fwd_k(const float* __restrict__ x, int ldx,
+                                                    float* __restrict__ y, int ldy,
+                                                    float* __restrict__ inv, unsigned Nb, unsigned H,
+                                                    unsigned W, unsigned C, int transpose_hw) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned rows = Nb * H * W;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (unsigned c = lane; c < C; c += 64) { const float v = xr[c]; s += v * v; }
+  s = so_wave_sum(s);
+  const float r = 1.0f / sqrtf(s + 1e-6f);
+  unsigned orow = row;
+  if (transpose_hw) {
+    const unsigned n = row / (H * W), rem = row - n * H * W;
+    const unsigned h = rem / W, w = rem - h * W;
+    orow = n * H * W + w * H + h;
+  }
+  float* yr = y + (size_t)orow * ldy;
+  for (unsigned c = lane; c < C; c += 64) yr[c] = xr[c] * r;
+  if (lane == 0) inv[row] = r;
+}
+
+// dx = (dy - y * <dy, y>) * inv      (y, dy read at the possibly transposed row)
+__global__ __launch_bounds__(256) void l2norm_bwd_k(const float* __restrict__ y, int ldy,
+                                                    const float* __restrict__ dy, int lddy,
+                                                    const float* __restrict__ inv,
+                                                    float* __restrict__ dx, int lddx, unsigned Nb,
+                                                    unsigned H, unsigned W, unsigned C,
+                                                    int transpose_hw) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned rows = Nb * H * W;
+  if (row >= rows) return;
+  unsigned orow = row;
+  if (transpose_hw) {
+    const unsigned n = row / (H * W), rem = row - n * H * W;
+    const unsigned h = rem / W, w = rem - h * W;
+    orow = n * H * W + w * H + h;
+  }
+  const float* yr = y + (size_t)orow * ldy;
+  const float* gr = dy + (size_t)orow * lddy;
+  float d = 0.f;
+  for (unsigned c = lane; c < C; c += 64) d += yr[c] * gr[c];
+  d = so_wave_sum(d);
+  const float r = inv[row];
+  float* o = dx + (size_t)row * lddx;
+  for (unsigned c = lane; c < C; c += 64) o[c] = (gr[c] - yr[c] * d) * r;
+}
+
+// ------------------------------------------------------------------ row softmax (attention)
+__global__ __launch_bounds__(256) void softmax_rows_fwd_k(const float* __restrict__ e, int lde,
+                                                          float* __restrict__ a, int lda,
+                                                          unsigned rows, unsigned Ncol) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* er = e + (size_t)row * lde;
+  float mx = -INFINITY;
+  for (unsigned c = lane; c < Ncol; c += 64) mx = fmaxf(mx, er[c]);
+  mx = so_wave_max(mx);
+  float s = 0.f;
+  for (unsigned c = lane; c < Ncol; c += 64) s += expf(er[c] - mx);
+  s = so_wave_sum(s);
+  const float r = 1.0f / s;
+  float* ar = a + (size_t)row * lda;
+  for (unsigned c = lane; c < Ncol; c += 64) ar[c] = expf(er[c] - mx) * r;
+}
+
+// dE = A * (dA - sum_j dA_j A_j)
+__global__ __launch_bounds__(256) void softmax_rows_bwd_k(const float* __restrict__ a, int lda,
+                                                          const float* __restrict__ da, int ldda,
+                                                          float* __restrict__ de, int ldde,
+                                                          unsigned rows, unsigned Ncol) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* ar = a + (size_t)row * lda;
+  const float* gr = da + (size_t)row * ldda;
+  float d = 0.f;
+  for (unsigned c = lane; c < Ncol; c += 64) d += ar[c] * gr[c];
+  d = so_wave_sum(d);
+  float* o = de + (size_t)row * ldde;
+  for (unsigned c = lane; c < Ncol; c += 64) o[c] = ar[c] * (gr[c] - d);
+}
+
+// ------------------------------------------------------------------ dot product (attention d gamma)
+__global__ __launch_bounds__(256) void dot_partial_k(const float* __restrict__ a, int lda,
+                                                     const float* __restrict__ b, int ldb,
+                                                     unsigned rows, unsigned C,
+                                                     float* __restrict__ part) {
+  __shared__ float red[4];
+  const unsigned total = rows * C;
+  float s = 0.f;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / C, c = idx - row * C;
+    s += a[(size_t)row * lda + c] * b[(size_t)row * ldb + c];
+  }
+  s = so_block_sum256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_final_k(const float* __restrict__ part, unsigned n,
+                                                   float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (unsigned i = threadIdx.x; i < n; i += 256) s += part[i];
+  s = so_block_sum256(s, red);
+  if (threadIdx.x == 0) out[0] = scale * s;
+}
+
+// ------------------------------------------------------------------ regression head: Linear(C*P -> J) + tanh
+// x: NHWC rows [b][p][c] (ldx); weight [J][C*P] with the reference's flatten order idx = c*P + p.
+__global__ __launch_bounds__(256) void linear_chw_fwd_k(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, unsigned P, unsigned C,
+                                                        unsigned J, int apply_tanh) {
+  __shared__ float red[4];
+  const unsigned b = blockIdx.y, j = blockIdx.x;
+  const unsigned K = P * C;
+  float s = 0.f;
+  for (unsigned t = threadIdx.x; t < K; t += 256) {
+    const unsigned p = t / C, c = t - p * C;  // NHWC order -> coalesced x reads
+    s += x[((size_t)b * P + p) * ldx + c] * w[(size_t)j * K + c * P + p];
+  }
+  s = so_block_sum256(s, red);
+  if (threadIdx.x == 0) {
+    s += bias[j];
+    y[(size_t)b * J + j] = apply_tanh ? tanhf(s) : s;
+  }
+}
+
+// dz = dy * (1 - y^2) (if tanh) ; dw[j][c*P+p] = sum_b dz[b][j] x[b][p][c] ; dbias[j] = sum_b dz[b][j]
+__global__ __launch_bounds__(256) void linear_chw_bwd_w_k(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ dy,
+                                                          float* __restrict__ dw,
+                                                          float* __restrict__ dbias, unsigned Nb,
+                                                          unsigned P, unsigned C, unsigned J,
+                                                          int apply_tanh) {
+  const unsigned K = P * C;
+  const unsigned total = J * K;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned j = idx / K, k = idx - j * K;
+    const unsigned c = k / P, p = k - c * P;
+    float s = 0.f, sb = 0.f;
+    for (unsigned b = 0; b < Nb; ++b) {
+      const float yv = y[(size_t)b * J + j];
+      const float dz = dy[(size_t)b * J + j] * (apply_tanh ? (1.f - yv * yv) : 1.f);
+      s += dz * x[((size_t)b * P + p) * ldx + c];
+      sb += dz;
+    }
+    dw[idx] = s;
+    if (k == 0) dbias[j] = sb;
+  }
+}
+
+// dx[b][p][c] = sum_j dz[b][j] w[j][c*P+p]
+__global__ __launch_bounds__(256) void linear_chw_bwd_x_k(const float* __restrict__ w,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int lddx,
+                                                          unsigned Nb, unsigned P, unsigned C,
+                                                          unsigned J, int apply_tanh) {
+  const unsigned K = P * C;
+  const unsigned total = Nb * K;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned b = idx / K, t = idx - b * K;
+    const unsigned p = t / C, c = t - p * C;
+    float s = 0.f;
+    for (unsigned j = 0; j < J; ++j) {
+      const float yv = y[(size_t)b * J + j];
+      const float dz = dy[(size_t)b * J + j] * (apply_tanh ? (1.f - yv * yv) : 1.f);
+      s += dz * w[(size_t)j * K + c * P + p];
+    }
+    dx[((size_t)b * P + p) * lddx + c] = s;
+  }
+}
+
+// ------------------------------------------------------------------ thin-plate-spline grid
+// coef[b][axis][i], i < NP+3:  Li[i][0:NP] . (theta[b][axis*NP + k] + Pbase[axis][k])
+// rows 0..NP-1 are the non-linear weights W, rows NP..NP+2 the affine part A (warp.py:231-268).
+__global__ __launch_bounds__(64) void tps_coef_k(const float* __restrict__ theta,
+                                                 const float* __restrict__ Li,
+                                                 const float* __restrict__ px,
+                                                 const float* __restrict__ py,
+                                                 float* __restrict__ coef, int NP) {
+  const int b = blockIdx.x;
+  const int L = NP + 3;
+  for (int t = threadIdx.x; t < 2 * L; t += 64) {
+    const int axis = t / L, i = t - axis * L;
+    const float* base = axis == 0 ? px : py;
+    float s = 0.f;
+    for (int k = 0; k < NP; ++k) s += Li[i * L + k] * (theta[(size_t)b * 2 * NP + axis * NP + k] + base[k]);
+    coef[((size_t)b * 2 + axis) * L + i] = s;
+  }
+}
+
+__device__ __forceinline__ float tps_u(float x, float y, float pxk, float pyk) {
+  const float dx = x - pxk, dy = y - pyk;
+  float d2 = dx * dx + dy * dy;
+  if (d2 == 0.f) d2 = 1.f;  // warp.py:288 (avoid log(0)); U = 0 there
+  return d2 * logf(d2);
+}
+
+// grid[b][h][w][0:2] = A0 + A1 x + A2 y + sum_k W_k U_k      (warp.py:304-318)
+__global__ __launch_bounds__(256) void tps_grid_fwd_k(const float* __restrict__ coef,
+                                                      const float* __restrict__ gx,
+                                                      const float* __restrict__ gy,
+                                                      const float* __restrict__ px,
+                                                      const float* __restrict__ py,
+                                                      float* __restrict__ grid, unsigned H,
+                                                      unsigned W, int NP) {
+  extern __shared__ float sh[];  // [2*L] coef + [NP] px + [NP] py
+  const int L = NP + 3;
+  const unsigned b = blockIdx.y;
+  for (int t = threadIdx.x; t < 2 * L; t += 256) sh[t] = coef[(size_t)b * 2 * L + t];
+  for (int t = threadIdx.x; t < NP; t += 256) { sh[2 * L + t] = px[t]; sh[2 * L + NP + t] = py[t]; }
+  __syncthreads();
+  const float* cx = sh;
+  const float* cy = sh + L;
+  const float* spx = sh + 2 * L;
+  const float* spy = sh + 2 * L + NP;
+  const unsigned pix = blockIdx.x * 256u + threadIdx.x;
+  if (pix >= H * W) return;
+  const unsigned h = pix / W, w = pix - h * W;
+  const float x = gx[w], y = gy[h];
+  float sx = 0.f, sy = 0.f;
+  for (int k = 0; k < NP; ++k) {
+    const float u = tps_u(x, y, spx[k], spy[k]);
+    sx += cx[k] * u;
+    sy += cy[k] * u;
+  }
+  const float ox = cx[NP] + cx[NP + 1] * x + cx[NP + 2] * y + sx;
+  const float oy = cy[NP] + cy[NP + 1] * x + cy[NP + 2] * y + sy;
+  float2 o = make_float2(ox, oy);
+  *reinterpret_cast<float2*>(grid + ((size_t)b * H * W + pix) * 2) = o;
+}
+
+// partial[b][blk][axis][i] = sum over the block's pixels of dgrid[b][pix][axis] * basis_i(pix)
+constexpr int TPS_PPT = 8;
+__global__ __launch_bounds__(256) void tps_grid_bwd_partial_k(const float* __restrict__ dgrid,
+                                                              const float* __restrict__ gx,
+                                                              const float* __restrict__ gy,
+                                                              const float* __restrict__ px,
+                                                              const float* __restrict__ py,
+                                                              float* __restrict__ part, unsigned H,
+                                                              unsigned W, int NP) {
+  __shared__ float red[4];
+  __shared__ float spx[64], spy[64];
+  const int L = NP + 3;
+  const unsigned b = blockIdx.y;
+  for (int t = threadIdx.x; t < NP; t += 256) { spx[t] = px[t]; spy[t] = py[t]; }
+  __syncthreads();
+  const unsigned HW = H * W;
+  const unsigned p0 = blockIdx.x * 256u * TPS_PPT;
+  float* out = part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * L;
+  // loop over basis functions; each pass re-reads the block's (L2-resident) gradients
+  for (int i = 0; i < L; ++i) {
+    float ax = 0.f, ay = 0.f;
+    for (int q = 0; q < TPS_PPT; ++q) {
+      const unsigned pix = p0 + q * 256u + threadIdx.x;
+      if (pix < HW) {
+        const unsigned h = pix / W, w = pix - h * W;
+        const float x = gx[w], y = gy[h];
+        float basis;
+        if (i < NP) basis = tps_u(x, y, spx[i], spy[i]);
+        else if (i == NP) basis = 1.f;
+        else if (i == NP + 1) basis = x;
+        else basis = y;
+        const float2 g = *reinterpret_cast<const float2*>(dgrid + ((size_t)b * HW + pix) * 2);
+        ax += g.x * basis;
+        ay += g.y * basis;
+      }
+    }
+    ax = so_block_sum256(ax, red);
+    ay = so_block_sum256(ay, red);
+    if (threadIdx.x == 0) { out[i] = ax; out[L + i] = ay; }
+  }
+}
+
+// dtheta[b][axis*NP + k] = sum_i Li[i][k] * (sum_blk partial[b][blk][axis][i])
+__global__ __launch_bounds__(64) void tps_grid_bwd_final_k(const float* __restrict__ part,
+                                                           unsigned nblk,
+                                                           const float* __restrict__ Li,
+                                                           float* __restrict__ dtheta, int NP) {
+  __shared__ float G[2 * 64];
+  const int L = NP + 3;
+  const unsigned b = blockIdx.x;
+  for (int t = threadIdx.x; t < 2 * L; t += 64) {
+    float s = 0.f;
+    for (unsigned k = 0; k < nblk; ++k) s += part[((size_t)b * nblk + k) * 2 * L + t];
+    G[t] = s;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * NP; t += 64) {
+    const int axis = t / NP, k = t - axis * NP;
+    float s = 0.f;
+    for (int i = 0; i < L; ++i) s += Li[i * L + k] * G[axis * L + i];
+    dtheta[(size_t)b * 2 * NP + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------ grid_sample (bilinear, align_corners=False)
+// Index arithmetic follows ATen's CPU kernel (GridSamplerKernel.cpp): ix = (x + 1) * (W / 2) - 0.5 with one
+// rounding per operation (no FMA contraction), border padding clamps the coordinate BEFORE floor.
+struct GsTap {
+  int x0, y0;          // north-west tap
+  float wx, wy;        // fractional weights (east / south)
+  bool gx_in, gy_in;   // coordinate strictly inside (0, max): gradient mask of the clamp
+};
+
+__device__ __forceinline__ GsTap gs_locate(float gxv, float gyv, int W, int H, int border) {
+  GsTap t;
+  float ix = __fsub_rn(__fmul_rn(__fadd_rn(gxv, 1.0f), (float)W * 0.5f), 0.5f);
+  float iy = __fsub_rn(__fmul_rn(__fadd_rn(gyv, 1.0f), (float)H * 0.5f), 0.5f);
+  t.gx_in = true; t.gy_in = true;
+  if (border) {
+    const float mx = (float)(W - 1), my = (float)(H - 1);
+    ix = fminf(mx, fmaxf(0.f, ix));  // NaN -> 0, like clamp_min(0, in)
+    iy = fminf(my, fmaxf(0.f, iy));
+    t.gx_in = (ix != 0.f) && (ix != mx);
+    t.gy_in = (iy != 0.f) && (iy != my);
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  t.x0 = (int)fx; t.y0 = (int)fy;
+  t.wx = __fsub_rn(ix, fx);
+  t.wy = __fsub_rn(iy, fy);
+  return t;
+}
+
+// input [B][C][H][W] planar, grid [B][Ho][Wo][2], out [B][C][Ho][Wo]; taps (optional) [B][Ho][Wo][2] int32 = (x0,y0)
+__global__ __launch_bounds__(256) void grid_sample_fwd_k(const float* __restrict__ in,
+                                                         const float* __restrict__ grid,
+                                                         float* __restrict__ out,
+                                                         int* __restrict__ taps, unsigned Nb,
+                                                         unsigned C, unsigned H, unsigned W,
+                                                         unsigned Ho, unsigned Wo, int border) {
+  const unsigned total = Nb * Ho * Wo;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned b = idx / (Ho * Wo), pix = idx - b * Ho * Wo;
+    const float2 g = *reinterpret_cast<const float2*>(grid + (size_t)idx * 2);
+    const GsTap t = gs_locate(g.x, g.y, (int)W, (int)H, border);
+    if (taps) { taps[(size_t)idx * 2] = t.x0; taps[(size_t)idx * 2 + 1] = t.y0; }
+    const float e = 1.f - t.wx, s = 1.f - t.wy;
+    const float nw = s * e, ne = s * t.wx, sw = t.wy * e, se = t.wy * t.wx;
+    const bool x0ok = (unsigned)t.x0 < W, x1ok = (unsigned)(t.x0 + 1) < W;
+    const bool y0ok = (unsigned)t.y0 < H, y1ok = (unsigned)(t.y0 + 1) < H;
+    for (unsigned c = 0; c < C; ++c) {
+      const float* p = in + ((size_t)b * C + c) * H * W;
+      const float vnw = (x0ok && y0ok) ? p[(size_t)t.y0 * W + t.x0] : 0.f;
+      const float vne = (x1ok && y0ok) ? p[(size_t)t.y0 * W + t.x0 + 1] : 0.f;
+      const float vsw = (x0ok && y1ok) ? p[(size_t)(t.y0 + 1) * W + t.x0] : 0.f;
+      const float vse = (x1ok && y1ok) ? p[(size_t)(t.y0 + 1) * W + t.x0 + 1] : 0.f;
+      out[((size_t)b * C + c) * Ho * Wo + pix] = vnw * nw + vne * ne + vsw * sw + vse * se;
+    }
+  }
+}
+
+// d grid (and optionally d input through atomics).  dgrid[B][Ho][Wo][2].
+__global__ __launch_bounds__(256) void grid_sample_bwd_k(const float* __restrict__ in,
+                                                         const float* __restrict__ grid,
+                                                         const float* __restrict__ dout,
+                                                         float* __restrict__ dgrid,
+                                                         float* __restrict__ din, unsigned Nb,
+                                                         unsigned C, unsigned H, unsigned W,
+                                                         unsigned Ho, unsigned Wo, int border) {
+  const unsigned total = Nb * Ho * Wo;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned b = idx / (Ho * Wo), pix = idx - b * Ho * Wo;
+    const float2 g = *reinterpret_cast<const float2*>(grid + (size_t)idx * 2);
+    const GsTap t = gs_locate(g.x, g.y, (int)W, (int)H, border);
+    const float e = 1.f - t.wx, s = 1.f - t.wy;
+    const bool x0ok = (unsigned)t.x0 < W, x1ok = (unsigned)(t.x0 + 1) < W;
+    const bool y0ok = (unsigned)t.y0 < H, y1ok = (unsigned)(t.y0 + 1) < H;
+    float gxa = 0.f, gya = 0.f;
+    for (unsigned c = 0; c < C; ++c) {
+      const float go = dout[((size_t)b * C + c) * Ho * Wo + pix];
+      const float* p = in + ((size_t)b * C + c) * H * W;
+      const float vnw = (x0ok && y0ok) ? p[(size_t)t.y0 * W + t.x0] : 0.f;
+      const float vne = (x1ok && y0ok) ? p[(size_t)t.y0 * W + t.x0 + 1] : 0.f;
+      const float vsw = (x0ok && y1ok) ? p[(size_t)(t.y0 + 1) * W + t.x0] : 0.f;
+      const float vse = (x1ok && y1ok) ? p[(size_t)(t.y0 + 1) * W + t.x0 + 1] : 0.f;
+      gxa += go * ((vne - vnw) * s + (vse - vsw) * t.wy);
+      gya += go * ((vsw - vnw) * e + (vse - vne) * t.wx);
+      if (din) {
+        float* q = din + ((size_t)b * C + c) * H * W;
+        if (x0ok && y0ok) atomicAdd(q + (size_t)t.y0 * W + t.x0, go * s * e);
+        if (x1ok && y0ok) atomicAdd(q + (size_t)t.y0 * W + t.x0 + 1, go * s * t.wx);
+        if (x0ok && y1ok) atomicAdd(q + (size_t)(t.y0 + 1) * W + t.x0, go * t.wy * e);
+        if (x1ok && y1ok) atomicAdd(q + (size_t)(t.y0 + 1) * W + t.x0 + 1, go * t.wy * t.wx);
+      }
+    }
+    if (dgrid) {
+      const float mx = t.gx_in ? (float)W * 0.5f : 0.f;
+      const float my = t.gy_in ? (float)H * 0.5f : 0.f;
+      *reinterpret_cast<float2*>(dgrid + (size_t)idx * 2) = make_float2(gxa * mx, gya * my);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ Resample2d (flow warp, kernel_size 1, bilinear)
+// Specification restated from the public NVIDIA flownet2-pytorch resample2d op (the reference's submodule
+// is empty here: parity unpinned).  in [B][C][H][W], flow [B][2][H][W] in pixels.
+__global__ __launch_bounds__(256) void resample2d_fwd_k(const float* __restrict__ in,
+                                                        const float* __restrict__ flow,
+                                                        float* __restrict__ out, unsigned Nb,
+                                                        unsigned C, unsigned H, unsigned W) {
+  const unsigned total = Nb * H * W;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned b = idx / (H * W), pix = idx - b * H * W;
+    const unsigned y = pix / W, x = pix - y * W;
+    const float xf = (float)x + flow[((size_t)b * 2) * H * W + pix];
+    const float yf = (float)y + flow[((size_t)b * 2 + 1) * H * W + pix];
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float a = xf - fx, bt = yf - fy;
+    const int xL = max(min((int)fx, (int)W - 1), 0), xR = max(min((int)fx + 1, (int)W - 1), 0);
+    const int yT = max(min((int)fy, (int)H - 1), 0), yB = max(min((int)fy + 1, (int)H - 1), 0);
+    for (unsigned c = 0; c < C; ++c) {
+      const float* p = in + ((size_t)b * C + c) * H * W;
+      out[((size_t)b * C + c) * H * W + pix] =
+          (1.f - a) * (1.f - bt) * p[(size_t)yT * W + xL] + a * (1.f - bt) * p[(size_t)yT * W + xR] +
+          (1.f - a) * bt * p[(size_t)yB * W + xL] + a * bt * p[(size_t)yB * W + xR];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void resample2d_bwd_k(const float* __restrict__ in,
+                                                        const float* __restrict__ flow,
+                                                        const float* __restrict__ dout,
+                                                        float* __restrict__ din,
+                                                        float* __restrict__ dflow, unsigned Nb,
+                                                        unsigned C, unsigned H, unsigned W) {
+  const unsigned total = Nb * H * W;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned b = idx / (H * W), pix = idx - b * H * W;
+    const unsigned y = pix / W, x = pix - y * W;
+    const float xf = (float)x + flow[((size_t)b * 2) * H * W + pix];
+    const float yf = (float)y + flow[((size_t)b * 2 + 1) * H * W + pix];
+    const float fx = floorf(xf), fy = floorf(yf);
+    const float a = xf - fx, bt = yf - fy;
+    const int xL = max(min((int)fx, (int)W - 1), 0), xR = max(min((int)fx + 1, (int)W - 1), 0);
+    const int yT = max(min((int)fy, (int)H - 1), 0), yB = max(min((int)fy + 1, (int)H - 1), 0);
+    float gfx = 0.f, gfy = 0.f;
+    for (unsigned c = 0; c < C; ++c) {
+      const float go = dout[((size_t)b * C + c) * H * W + pix];
+      const float* p = in + ((size_t)b * C + c) * H * W;
+      const float vTL = p[(size_t)yT * W + xL], vTR = p[(size_t)yT * W + xR];
+      const float vBL = p[(size_t)yB * W + xL], vBR = p[(size_t)yB * W + xR];
+      gfx += go * ((1.f - bt) * (vTR - vTL) + bt * (vBR - vBL));
+      gfy += go * ((1.f - a) * (vBL - vTL) + a * (vBR - vTR));
+      if (din) {
+        float* q = din + ((size_t)b * C + c) * H * W;
+        atomicAdd(q + (size_t)yT * W + xL, go * (1.f - a) * (1.f - bt));
+        atomicAdd(q + (size_t)yT * W + xR, go * a * (1.f - bt));
+        atomicAdd(q + (size_t)yB * W + xL, go * (1.f - a) * bt);
+        atomicAdd(q + (size_t)yB * W + xR, go * a * bt);
+      }
+    }
+    if (dflow) {
+      dflow[((size_t)b * 2) * H * W + pix] = gfx;
+      dflow[((size_t)b * 2 + 1) * H * W + pix] = gfy;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int so_l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* inv, int Nb, int H, int W, int C,
+                  int transpose_hw, void* stream) {
+  const long long rows = (long long)Nb * H * W;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_fwd_k, dim3(so_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, y,
+                     ldy, inv, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, transpose_hw);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_l2norm_bwd(const float* y, int ldy, const float* dy, int lddy, const float* inv, float* dx,
+                  int lddx, int Nb, int H, int W, int C, int transpose_hw, void* stream) {
+  const long long rows = (long long)Nb * H * W;
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(l2norm_bwd_k, dim3(so_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                     dy, lddy, inv, dx, lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C,
+                     transpose_hw);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_softmax_rows_fwd(const float* e, int lde, float* a, int lda, long long rows, int ncol,
+                        void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_fwd_k, dim3(so_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, e,
+                     lde, a, lda, (unsigned)rows, (unsigned)ncol);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_softmax_rows_bwd(const float* a, int lda, const float* da, int ldda, float* de, int ldde,
+                        long long rows, int ncol, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_bwd_k, dim3(so_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a,
+                     lda, da, ldda, de, ldde, (unsigned)rows, (unsigned)ncol);
+  return SO_LAUNCH_CHECK();
+}
+
+// ws: >= 1024 floats
+int so_dot(const float* a, int lda, const float* b, int ldb, long long rows, int C, float scale,
+           float* out, float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = grid_for(rows * C);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(dot_partial_k, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
+                     (unsigned)C, ws);
+  hipLaunchKernelGGL(sum_final_k, dim3(1), dim3(256), 0, st, ws, (unsigned)blocks, scale, out);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_linear_chw_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int Nb,
+                      int P, int C, int J, int apply_tanh, void* stream) {
+  hipLaunchKernelGGL(linear_chw_fwd_k, dim3(J, Nb), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias,
+                     y, (unsigned)P, (unsigned)C, (unsigned)J, apply_tanh);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_linear_chw_bwd(const float* x, int ldx, const float* w, const float* y, const float* dy,
+                      float* dx, int lddx, float* dw, float* dbias, int Nb, int P, int C, int J,
+                      int apply_tanh, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_chw_bwd_w_k, dim3(grid_for((long long)J * P * C)), dim3(256), 0, st, x, ldx,
+                     y, dy, dw, dbias, (unsigned)Nb, (unsigned)P, (unsigned)C, (unsigned)J, apply_tanh);
+  if (dx)
+    hipLaunchKernelGGL(linear_chw_bwd_x_k, dim3(grid_for((long long)Nb * P * C)), dim3(256), 0, st, w,
+                       y, dy, dx, lddx, (unsigned)Nb, (unsigned)P, (unsigned)C, (unsigned)J,
+                       apply_tanh);
+  return SO_LAUNCH_CHECK();
+}
+
+long long so_tps_ws_floats(int Nb, int H, int W, int NP) {
+  const int nblk = so_cdiv((long long)H * W, 256 * TPS_PPT);
+  return (long long)Nb * 2 * (NP + 3) + (long long)Nb * nblk * 2 * (NP + 3);
+}
+
+// theta [B][2*NP]; Li [(NP+3)][(NP+3)]; px,py [NP]; gx [W]; gy [H]; grid [B][H][W][2]
+int so_tps_grid_fwd(const float* theta, const float* Li, const float* px, const float* py,
+                    const float* gx, const float* gy, float* grid, int Nb, int H, int W, int NP,
+                    float* ws, void* stream) {
+  if (NP > 61) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = ws;
+  hipLaunchKernelGGL(tps_coef_k, dim3(Nb), dim3(64), 0, st, theta, Li, px, py, coef, NP);
+  const size_t sh = (size_t)(2 * (NP + 3) + 2 * NP) * sizeof(float);
+  hipLaunchKernelGGL(tps_grid_fwd_k, dim3(so_cdiv((long long)H * W, 256), Nb), dim3(256), sh, st, coef,
+                     gx, gy, px, py, grid, (unsigned)H, (unsigned)W, NP);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_tps_grid_bwd(const float* dgrid, const float* Li, const float* px, const float* py,
+                    const float* gx, const float* gy, float* dtheta, int Nb, int H, int W, int NP,
+                    float* ws, void* stream) {
+  if (NP > 61) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = so_cdiv((long long)H * W, 256 * TPS_PPT);
+  float* part = ws + (size_t)Nb * 2 * (NP + 3);
+  hipLaunchKernelGGL(tps_grid_bwd_partial_k, dim3(nblk, Nb), dim3(256), 0, st, dgrid, gx, gy, px, py,
+                     part, (unsigned)H, (unsigned)W, NP);
+  hipLaunchKernelGGL(tps_grid_bwd_final_k, dim3(Nb), dim3(64), 0, st, part, (unsigned)nblk, Li, dtheta,
+                     NP);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_grid_sample_fwd(const float* in, const float* grid, float* out, int* taps, int Nb, int C, int H,
+                       int W, int Ho, int Wo, int border, void* stream) {
+  const long long total = (long long)Nb * Ho * Wo;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(grid_sample_fwd_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     grid, out, taps, (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W,
+                     (unsigned)Ho, (unsigned)Wo, border);
+  return SO_LAUNCH_CHECK();
+}
+
+// din (optional) must be zero-filled by the caller; it is accumulated with atomics.
+int so_grid_sample_bwd(const float* in, const float* grid, const float* dout, float* dgrid, float* din,
+                       int Nb, int C, int H, int W, int Ho, int Wo, int border, void* stream) {
+  const long long total = (long long)Nb * Ho * Wo;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(grid_sample_bwd_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     grid, dout, dgrid, din, (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W,
+                     (unsigned)Ho, (unsigned)Wo, border);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_resample2d_fwd(const float* in, const float* flow, float* out, int Nb, int C, int H, int W,
+                      void* stream) {
+  const long long total = (long long)Nb * H * W;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(resample2d_fwd_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     flow, out, (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W);
+  return SO_LAUNCH_CHECK();
+}
+
+// din (optional) must be zero-filled by the caller; dflow optional.
+int so_resample2d_bwd(const float* in, const float* flow, const float* dout, float* din, float* dflow,
+                      int Nb, int C, int H, int W, void* stream) {
+  const long long total = (long long)Nb * H * W;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(resample2d_bwd_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     flow, dout, din, dflow, (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W);
+  return SO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

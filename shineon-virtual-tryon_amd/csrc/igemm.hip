@@ -1,0 +1,594 @@
+// fp32 MFMA implicit-GEMM engine for gfx950 (MI355X).
+//
+// One kernel template covers every contraction on the try-on hot path:
+//   FPROP : y[pix][ko]      = sum_{r,s,c} x[pix@(r,s)][c] * w[ko][r][s][c]      (Conv2d forward)
+//   DGRAD : dx[pix][c]      = sum_{r,s,ko} dy[pix'@(r,s)][ko] * w[ko][r][s][c]  (Conv2d input gradient,
+//                             strided convs are split in stride^2 parity classes so no zero taps are multiplied)
+//   WGRAD : dw[ko][r][s][c] = sum_{pix} dy[pix][ko] * x[pix@(r,s)][c]           (Conv2d weight gradient)
+//   GEMM  : batched C = op(A) op(B) for attention (QK^T, AV and their gradients) and the
+//           feature-correlation volume.
+// Reference ops replaced: torch conv2d / bmm as used by models/networks/cpvton/unet.py:129-174,
+// models/networks/cpvton/warp.py:9-99, models/networks/attention/sagan.py:38-50, models/networks/vgg.py:6-36.
+//
+// Design (CDNA4):
+//   * activations NHWC, weights OHWI  -> the GEMM K axis (channels within a filter tap) is contiguous in
+//     HBM for both operands: every global load is a 16-byte quad, 8 lanes cover one 128-byte line.
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  K may be permuted freely as long as A and B
+//     agree, so a lane-half reads FOUR consecutive k with one ds_read_b128 and feeds four MFMAs
+//     (k = kbase + 4*(lane>>5) + t for MFMA t).
+//   * two operand staging modes in LDS:
+//       KC ("k-contiguous")  : tile [rows][32 k] with row stride 36 floats -> conflict-free ds_read_b128
+//       MC ("mn-contiguous") : tile [32 k][rows]                          -> conflict-free ds_read_b32
+//     FPROP = KC x KC, DGRAD = KC x MC (weights read in place, no transposed copy), WGRAD = MC x MC.
+//   * 256 threads = 4 waves (2x2), block tile 128x128 or 64x64, BK = 32, double-buffered LDS with the
+//     next tile's global loads in flight in registers while the current tile is multiplied
+//     (one barrier per K tile).
+//   * deterministic split-K (slabs in a workspace + reduce kernel carrying the fused epilogue) for the
+//     tiny-spatial layers and for WGRAD, where the reduction axis is the pixel count.
+//   * fused epilogue: alpha (device scalar, attention gamma) * acc + bias[n] + residual, then activation.
+#include "common.h"
+#include "../../include/shineon_hip.h"
+
+enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_GEMM = 3 };
+
+struct SoIgemm {
+  const float* a;
+  const float* b;
+  float* c;
+  float* ws;
+  const float* bias;
+  const float* alpha;
+  const float* res;
+  int M, N, K;
+  int lda, ldb, ldc, ldres;
+  int Nb, H, W, C;   // input-side tensor (x / dx)
+  int Ho, Wo, Ko;    // output-side tensor (y / dy)
+  int R, S, stride, pad;
+  int TS;            // DGRAD: taps per class along W (= S / stride)
+  int H2, W2;        // DGRAD: class grid (= H / stride, W / stride)
+  int act;
+  float act_param;
+  int splitk, ktps, nclass;
+  long long sa, sb, sc, sres;  // GEMM batch strides in elements
+};
+
+__device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long long res_off, int n) {
+  if (p.alpha) v *= p.alpha[0];
+  if (p.bias) v += p.bias[n];
+  if (p.res) v += p.res[res_off + n];
+  return so_actf(p.act, v, p.act_param);
+}
+
+// Row index of the GEMM -> element offset of that output row (and of the residual row).
+template <int MODE>
+__device__ __forceinline__ void so_row_offset(const SoIgemm& p, int cls, int m, long long& off,
+                                              long long& roff) {
+  if constexpr (MODE == MODE_DGRAD) {
+    if (p.nclass > 1) {
+      const int ph = cls / p.stride, pw = cls - ph * p.stride;
+      const int hw2 = p.H2 * p.W2;
+      const int n = m / hw2;
+      const int rem = m - n * hw2;
+      const int h2 = rem / p.W2;
+      const int w2 = rem - h2 * p.W2;
+      const long long pix = ((long long)n * p.H + (h2 * p.stride + ph)) * p.W + (w2 * p.stride + pw);
+      off = pix * p.ldc;
+      roff = pix * p.ldres;
+      return;
+    }
+    off = (long long)m * p.ldc;
+    roff = (long long)m * p.ldres;
+  } else if constexpr (MODE == MODE_GEMM) {
+    off = (long long)cls * p.sc + (long long)m * p.ldc;
+    roff = (long long)cls * p.sres + (long long)m * p.ldres;
+  } else {
+    off = (long long)m * p.ldc;
+    roff = (long long)m * p.ldres;
+  }
+}
+
+template <int MODE, bool A_MC, bool B_MC, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
+  constexpr int BK = 32;
+  constexpr int LDK = 36;  // KC row stride: 144 B -> 16 lanes of a ds_read_b128 group hit 16 distinct slots
+  constexpr int A_STAGE = A_MC ? BK * BM : BM * LDK;
+  constexpr int B_STAGE = B_MC ? BK * BN : BN * LDK;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AJ = BM / 32, BJ = BN / 32;  // 16-byte quads staged per thread per K tile
+  constexpr int AQPR = BM / 4, BQPR = BN / 4;  // MC mode: quads per k-row
+  constexpr int ARPP = 256 / AQPR, BRPP = 256 / BQPR;  // MC mode: k-rows covered per pass
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int cls = blockIdx.z / p.splitk;
+  const int split = blockIdx.z - cls * p.splitk;
+
+  const float* __restrict__ gA = p.a;
+  const float* __restrict__ gB = p.b;
+  if constexpr (MODE == MODE_GEMM) {
+    gA += (long long)cls * p.sa;
+    gB += (long long)cls * p.sb;
+  }
+
+  // DGRAD parity class constants
+  int d_r0 = 0, d_s0 = 0, d_oh = 0, d_ow = 0;
+  if constexpr (MODE == MODE_DGRAD) {
+    const int ph = cls / p.stride, pw = cls - ph * p.stride;
+    d_r0 = (ph + p.pad) % p.stride;
+    d_s0 = (pw + p.pad) % p.stride;
+    d_oh = (ph + p.pad - d_r0) / p.stride;
+    d_ow = (pw + p.pad - d_s0) / p.stride;
+  }
+
+  // ---------------- per-thread loader state -----------------
+  const int kq = tid & 7;        // KC: quad within the 32-wide k row
+  const int krow8 = tid >> 3;    // KC: row within a 32-row pass
+  // A operand
+  int a_base[AJ], a_h0[AJ], a_w0[AJ];
+  (void)a_base; (void)a_h0; (void)a_w0;
+  if constexpr (!A_MC) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = m0 + krow8 + 32 * j;
+      a_base[j] = 0; a_h0[j] = -(1 << 28); a_w0[j] = 0;
+      if (m < p.M) {
+        if constexpr (MODE == MODE_FPROP) {
+          const int hw = p.Ho * p.Wo;
+          const int n = m / hw;
+          const int rem = m - n * hw;
+          const int ho = rem / p.Wo;
+          const int wo = rem - ho * p.Wo;
+          a_base[j] = n * p.H;
+          a_h0[j] = ho * p.stride - p.pad;
+          a_w0[j] = wo * p.stride - p.pad;
+        } else if constexpr (MODE == MODE_DGRAD) {
+          const int hw2 = p.H2 * p.W2;
+          const int n = m / hw2;
+          const int rem = m - n * hw2;
+          const int h2 = rem / p.W2;
+          const int w2 = rem - h2 * p.W2;
+          a_base[j] = n * p.Ho;
+          a_h0[j] = h2 + d_oh;
+          a_w0[j] = w2 + d_ow;
+        } else {  // GEMM KC
+          a_base[j] = m;
+          a_h0[j] = 0;
+        }
+      }
+    }
+  }
+  const int a_mq = tid % AQPR, a_kr = tid / AQPR;  // MC mapping
+  // B operand
+  const int b_mq = tid % BQPR, b_kr = tid / BQPR;
+  int b_r = 0, b_s = 0, b_c = 0;  // WGRAD: fixed filter tap / channel of this thread's column quad
+  bool b_colvalid = true;
+  if constexpr (MODE == MODE_WGRAD) {
+    const int nn = n0 + b_mq * 4;
+    b_colvalid = nn < p.N;
+    const int tap = nn / p.C;
+    b_c = nn - tap * p.C;
+    b_r = tap / p.S;
+    b_s = tap - b_r * p.S;
+  }
+
+  f32x4 ra[AJ], rb[BJ];
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    // ---------------- A ----------------
+    if constexpr (!A_MC) {
+      const int kk = k0 + kq * 4;
+      const bool kvalid = kk < p.K;
+      int t_r = 0, t_s = 0, t_c = kk;
+      if constexpr (MODE == MODE_FPROP) {
+        const int tap = kk / p.C;
+        t_c = kk - tap * p.C;
+        t_r = tap / p.S;
+        t_s = tap - t_r * p.S;
+      } else if constexpr (MODE == MODE_DGRAD) {
+        const int tapi = kk / p.Ko;
+        t_c = kk - tapi * p.Ko;
+        t_r = tapi / p.TS;
+        t_s = tapi - t_r * p.TS;
+      }
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == MODE_FPROP) {
+          const int hi = a_h0[j] + t_r, wi = a_w0[j] + t_s;
+          if (kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+            const long long off = ((long long)(a_base[j] + hi) * p.W + wi) * p.lda + t_c;
+            v = *reinterpret_cast<const f32x4*>(gA + off);
+          }
+        } else if constexpr (MODE == MODE_DGRAD) {
+          const int ho = a_h0[j] - t_r, wo = a_w0[j] - t_s;
+          if (kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo) {
+            const long long off = ((long long)(a_base[j] + ho) * p.Wo + wo) * p.lda + t_c;
+            v = *reinterpret_cast<const f32x4*>(gA + off);
+          }
+        } else {
+          if (kvalid && a_h0[j] == 0) {
+            const long long off = (long long)a_base[j] * p.lda + kk;
+            v = *reinterpret_cast<const f32x4*>(gA + off);
+          }
+        }
+        ra[j] = v;
+      }
+    } else {
+      const int col = m0 + a_mq * 4;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int kk = k0 + a_kr + ARPP * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kk < p.K && col < p.M) {
+          const long long off = (long long)kk * p.lda + col;
+          v = *reinterpret_cast<const f32x4*>(gA + off);
+        }
+        ra[j] = v;
+      }
+    }
+    // ---------------- B ----------------
+    if constexpr (!B_MC) {
+      const int kk = k0 + kq * 4;
+      const bool kvalid = kk < p.K;
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        const int n = n0 + krow8 + 32 * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kvalid && n < p.N) {
+          const long long off = (long long)n * p.ldb + kk;
+          v = *reinterpret_cast<const f32x4*>(gB + off);
+        }
+        rb[j] = v;
+      }
+    } else {
+      const int col = n0 + b_mq * 4;
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        const int kk = k0 + b_kr + BRPP * j;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == MODE_DGRAD) {
+          if (kk < p.K && col < p.N) {
+            const int tapi = kk / p.Ko;
+            const int ko = kk - tapi * p.Ko;
+            const int tr = tapi / p.TS;
+            const int ts = tapi - tr * p.TS;
+            const int r = d_r0 + p.stride * tr, s = d_s0 + p.stride * ts;
+            const long long off = ((long long)ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col;
+            v = *reinterpret_cast<const f32x4*>(gB + off);
+          }
+        } else if constexpr (MODE == MODE_WGRAD) {
+          if (kk < p.K && b_colvalid) {
+            const int hw = p.Ho * p.Wo;
+            const int n = kk / hw;
+            const int rem = kk - n * hw;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            const int hi = ho * p.stride - p.pad + b_r;
+            const int wi = wo * p.stride - p.pad + b_s;
+            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+              const long long off = ((long long)(n * p.H + hi) * p.W + wi) * p.ldb + b_c;
+              v = *reinterpret_cast<const f32x4*>(gB + off);
+            }
+          }
+        } else {
+          if (kk < p.K && col < p.N) {
+            const long long off = (long long)kk * p.ldb + col;
+            v = *reinterpret_cast<const f32x4*>(gB + off);
+          }
+        }
+        rb[j] = v;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int st) {
+    float* as = As + st * A_STAGE;
+    float* bs = Bs + st * B_STAGE;
+    if constexpr (!A_MC) {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+        *reinterpret_cast<f32x4*>(as + (krow8 + 32 * j) * LDK + kq * 4) = ra[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < AJ; ++j)
+        *reinterpret_cast<f32x4*>(as + (a_kr + ARPP * j) * BM + a_mq * 4) = ra[j];
+    }
+    if constexpr (!B_MC) {
+#pragma unroll
+      for (int j = 0; j < BJ; ++j)
+        *reinterpret_cast<f32x4*>(bs + (krow8 + 32 * j) * LDK + kq * 4) = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < BJ; ++j)
+        *reinterpret_cast<f32x4*>(bs + (b_kr + BRPP * j) * BN + b_mq * 4) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_begin = split * p.ktps;
+  int kt_end = kt_begin + p.ktps;
+  if (kt_end > nkt) kt_end = nkt;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1) < kt_end;
+    if (more) load_tiles(kt + 1);
+
+    const float* as = As + cur * A_STAGE;
+    const float* bs = Bs + cur * B_STAGE;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (!A_MC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(as + (wm * WTM + i * 32 + li) * LDK + kc * 8 + lh * 4);
+          af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[i][t] = as[(kc * 8 + lh * 4 + t) * BM + wm * WTM + i * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (!B_MC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(bs + (wn * WTN + j * 32 + li) * LDK + kc * 8 + lh * 4);
+          bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kc * 8 + lh * 4 + t) * BN + wn * WTN + j * 32 + li];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------- epilogue ----------------
+  const bool to_ws = p.splitk > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + wm * WTM + i * 32 + row;
+      if (m >= p.M) continue;
+      if (to_ws) {
+        float* dst = p.ws + ((long long)blockIdx.z * p.M + m) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WTN + j * 32 + li;
+          if (n < p.N) dst[n] = acc[i][j][r];
+        }
+      } else {
+        long long off, roff;
+        so_row_offset<MODE>(p, cls, m, off, roff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * WTN + j * 32 + li;
+          if (n < p.N) p.c[off + n] = so_epilogue(p, acc[i][j][r], roff, n);
+        }
+      }
+    }
+  }
+}
+
+// Sums the split-K slabs ws[cls][split][M][N] in split order (deterministic) and applies the epilogue.
+template <int MODE>
+__global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) {
+  const long long total = (long long)p.nclass * p.M * p.N;
+  const long long mn = (long long)p.M * p.N;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int cls = (int)(idx / mn);
+    const long long rem = idx - (long long)cls * mn;
+    const int m = (int)(rem / p.N);
+    const int n = (int)(rem - (long long)m * p.N);
+    const float* src = p.ws + (long long)cls * p.splitk * mn + rem;
+    float v = 0.f;
+    for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * mn];
+    long long off, roff;
+    so_row_offset<MODE>(p, cls, m, off, roff);
+    p.c[off + n] = so_epilogue(p, v, roff, n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side: tile / split-K selection and launch.
+// ------------------------------------------------------------------------------------------------
+struct SoPlan {
+  int bm, splitk, ktps;
+};
+
+static SoPlan so_plan(const SoIgemm& p, long long ws_floats, int force_bm, int force_splitk) {
+  const int nkt = so_cdiv(p.K, 32);
+  SoPlan best = {64, 1, nkt};
+  double best_cost = 1e30;
+  const int bms[2] = {128, 64};
+  for (int bi = 0; bi < 2; ++bi) {
+    const int bm = bms[bi];
+    if (force_bm && bm != force_bm) continue;
+    const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bm) * p.nclass;
+    for (int sk = 1; sk <= 256; sk *= 2) {
+      if (force_splitk && sk != force_splitk) continue;
+      if (sk > nkt) break;
+      const int ktps = so_cdiv(nkt, sk);
+      const int sk_eff = so_cdiv(nkt, ktps);
+      if (sk_eff > 1 && (long long)sk_eff * p.nclass * p.M * p.N > ws_floats) continue;
+      const long long blocks = tiles * sk_eff;
+      // per-CU MFMA time for one K tile of this block shape (0.6 TFLOP/s per CU at ~75 %)
+      const double t_kt = 2.0 * bm * bm * 32 / (0.6e12 * 0.75) * (bm == 64 ? 1.12 : 1.0);
+      const double waves = (double)((blocks + 255) / 256);
+      double cost = waves * (ktps + 3) * t_kt;
+      if (sk_eff > 1) cost += 3e-6 + (double)(sk_eff + 1) * p.nclass * p.M * p.N * 4.0 / 3e12;
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = {bm, sk_eff, ktps};
+      }
+    }
+  }
+  return best;
+}
+
+static int g_force_bm = 0, g_force_splitk = 0;
+
+template <int MODE, bool A_MC, bool B_MC, int BM>
+static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
+  constexpr int A_STAGE = A_MC ? 32 * BM : BM * 36;
+  constexpr int B_STAGE = B_MC ? 32 * BM : BM * 36;
+  constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
+  auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BM);
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.nclass * p.splitk));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+  int err = SO_LAUNCH_CHECK();
+  if (err) return err;
+  if (p.splitk > 1) {
+    const long long total = (long long)p.nclass * p.M * p.N;
+    int blocks = so_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(so_splitk_reduce_kernel<MODE>, dim3(blocks), dim3(256), 0, stream, p);
+    err = SO_LAUNCH_CHECK();
+  }
+  return err;
+}
+
+template <int MODE, bool A_MC, bool B_MC>
+static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return 0;
+  const SoPlan plan = so_plan(p, p.ws ? ws_bytes / 4 : 0, g_force_bm, g_force_splitk);
+  p.splitk = plan.splitk;
+  p.ktps = plan.ktps;
+  if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128>(p, stream);
+  return so_launch_tile<MODE, A_MC, B_MC, 64>(p, stream);
+}
+
+static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" {
+
+void so_igemm_force(int bm, int splitk) {
+  g_force_bm = bm;
+  g_force_splitk = splitk;
+}
+
+int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
+                    float act_param, float* ws, long long ws_bytes, void* stream) {
+  if ((C & 3) || (ldx & 3) || !so_aligned16(x) || !so_aligned16(w)) return SO_ERR_ALIGN;
+  SoIgemm p = {};
+  p.a = x; p.b = w; p.c = y; p.ws = ws; p.bias = bias;
+  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.M = Nb * p.Ho * p.Wo; p.N = Ko; p.K = R * S * C;
+  p.lda = ldx; p.ldb = p.K; p.ldc = ldy; p.ldres = 0;
+  p.act = act; p.act_param = act_param; p.nclass = 1;
+  return so_launch<MODE_FPROP, false, false>(p, ws_bytes, (hipStream_t)stream);
+}
+
+int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nb, int H,
+                    int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                    long long ws_bytes, void* stream) {
+  if ((Ko & 3) || (lddy & 3) || (C & 3) || !so_aligned16(dy) || !so_aligned16(w)) return SO_ERR_ALIGN;
+  if ((R % stride) || (S % stride) || (H % stride) || (W % stride)) return SO_ERR_SHAPE;
+  SoIgemm p = {};
+  p.a = dy; p.b = w; p.c = dx; p.ws = ws;
+  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.TS = S / stride; p.H2 = H / stride; p.W2 = W / stride;
+  p.nclass = stride * stride;
+  p.M = Nb * p.H2 * p.W2; p.N = C; p.K = (R / stride) * (S / stride) * Ko;
+  p.lda = lddy; p.ldb = C; p.ldc = lddx; p.ldres = 0;
+  p.act = SO_ACT_NONE;
+  return so_launch<MODE_DGRAD, false, true>(p, ws_bytes, (hipStream_t)stream);
+}
+
+int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,
+                    int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                    long long ws_bytes, void* stream) {
+  if ((Ko & 3) || (lddy & 3) || (C & 3) || (ldx & 3) || !so_aligned16(dy) || !so_aligned16(x))
+    return SO_ERR_ALIGN;
+  SoIgemm p = {};
+  p.a = dy; p.b = x; p.c = dw; p.ws = ws;
+  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.M = Ko; p.N = R * S * C; p.K = Nb * p.Ho * p.Wo;
+  p.lda = lddy; p.ldb = ldx; p.ldc = p.N; p.ldres = 0;
+  p.act = SO_ACT_NONE; p.nclass = 1;
+  return so_launch<MODE_WGRAD, true, true>(p, ws_bytes, (hipStream_t)stream);
+}
+
+int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A, int lda,
+                    long long sa, const float* B, int ldb, long long sb, float* C, int ldc,
+                    long long sc, int batch, const float* alpha, const float* bias,
+                    const float* res, int ldres, long long sres, int act, float act_param,
+                    float* ws, long long ws_bytes, void* stream) {
+  // C[b] (MxN) = act(alpha * opA(A[b]) opB(B[b]) + bias[n] + res[b])
+  //   transa == 0: A is [M][K] row-major (lda);  transa == 1: A is [K][M] row-major
+  //   transb == 0: B is [K][N] row-major (ldb);  transb == 1: B is [N][K] row-major
+  if (!so_aligned16(A) || !so_aligned16(B) || (lda & 3) || (ldb & 3) || (sa & 3) || (sb & 3))
+    return SO_ERR_ALIGN;
+  if ((transa ? (M & 3) : (K & 3)) || (transb ? (K & 3) : (N & 3))) return SO_ERR_ALIGN;
+  SoIgemm p = {};
+  p.a = A; p.b = B; p.c = C; p.ws = ws; p.alpha = alpha; p.bias = bias; p.res = res;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
+  p.sa = sa; p.sb = sb; p.sc = sc; p.sres = sres;
+  p.act = act; p.act_param = act_param; p.nclass = batch;
+  p.stride = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (!transa && transb) return so_launch<MODE_GEMM, false, false>(p, ws_bytes, st);
+  if (!transa && !transb) return so_launch<MODE_GEMM, false, true>(p, ws_bytes, st);
+  if (transa && !transb) return so_launch<MODE_GEMM, true, true>(p, ws_bytes, st);
+  return SO_ERR_SHAPE;
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// InstanceNorm2d / BatchNorm2d (training and inference) forward + backward for NHWC rows (gfx950).
+//
+// Reference semantics (file:line in /root/reference):
+//   nn.InstanceNorm2d(affine=False, eps=1e-5, no running stats)  models/networks/cpvton/unet.py:136,143-146
+//        (U-Net norm layer: models/unet_mask_model.py:56)
+//   nn.BatchNorm2d (train: batch statistics over N,H,W, biased variance for normalisation, unbiased for
+//        running_var, momentum 0.1, eps 1e-5, affine)              models/networks/cpvton/warp.py:15,21,29,75-84
+//
+// A "group" is one statistics domain: one sample for InstanceNorm (G = N, R = H*W rows), the whole
+// batch for BatchNorm (G = 1, R = N*H*W rows).  Statistics are column reductions of an [R][C] matrix:
+// consecutive lanes own consecutive channels (coalesced), several row-lanes stride over the rows,
+// partial (count, mean, M2) triples are merged with Chan's formula in a fixed order (deterministic,
+// no cancellation: per-thread sums are shifted by the first element seen).
+#include "common.h"
+#include "../../include/shineon_hip.h"
+
+namespace {
+
+struct Mom {
+  float n, mean, m2;
+};
+
+__device__ __forceinline__ Mom mom_merge(Mom a, Mom b) {
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  Mom r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  r.mean = a.mean + d * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  return r;
+}
+
+constexpr int EPT = 32;  // rows per thread per chunk
+
+// part layout: [G][nchunk][3][C]
+__global__ __launch_bounds__(256) void stats_partial_k(const float* __restrict__ x, int ldx,
+                                                       unsigned R, unsigned C, unsigned chunk,
+                                                       unsigned nchunk, float* __restrict__ part) {
+  __shared__ float sn[256], sm[256], s2[256];
+  const unsigned CPB = C >= 256 ? 256 : C;
+  const unsigned RL = 256 / CPB;
+  const unsigned tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
+  const unsigned col = blockIdx.y * CPB + tx;
+  const unsigned g = blockIdx.z;
+  const unsigned r0 = blockIdx.x * chunk;
+  unsigned r1 = r0 + chunk;
+  if (r1 > R) r1 = R;
+  const float* base = x + (size_t)g * R * ldx;
+  float cnt = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
+  if (ty < RL && col < C) {
+    for (unsigned r = r0 + ty; r < r1; r += RL) {
+      const float v = base[(size_t)r * ldx + col];
+      if (cnt == 0.f) shift = v;
+      const float d = v - shift;
+      s += d;
+      ss += d * d;
+      cnt += 1.f;
+    }
+  }
+  float mean = 0.f, m2 = 0.f;
+  if (cnt > 0.f) {
+    mean = shift + s / cnt;
+    m2 = ss - s * s / cnt;
+    if (m2 < 0.f) m2 = 0.f;
+  }
+  sn[threadIdx.x] = cnt; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
+  __syncthreads();
+  if (ty == 0 && col < C) {
+    Mom acc = {0.f, 0.f, 0.f};
+    for (unsigned l = 0; l < RL; ++l) {
+      const unsigned i = l * CPB + tx;
+      acc = mom_merge(acc, Mom{sn[i], sm[i], s2[i]});
+    }
+    float* o = part + ((size_t)g * nchunk + blockIdx.x) * 3 * C;
+    o[col] = acc.n; o[C + col] = acc.mean; o[2 * C + col] = acc.m2;
+  }
+}
+
+// mean[g][c], rstd[g][c]; optional running-stat update (BatchNorm, G must be 1).
+__global__ __launch_bounds__(256) void stats_final_k(const float* __restrict__ part, unsigned nchunk,
+                                                     unsigned C, float eps, float* __restrict__ mean,
+                                                     float* __restrict__ rstd,
+                                                     float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float momentum) {
+  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= C) return;
+  Mom acc = {0.f, 0.f, 0.f};
+  for (unsigned k = 0; k < nchunk; ++k) {
+    const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
+    acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
+  }
+  const float var = acc.m2 / acc.n;
+  mean[(size_t)g * C + c] = acc.mean;
+  rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = acc.n > 1.f ? acc.m2 / (acc.n - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * acc.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// y = (x - mean) * rstd * gamma + beta  (gamma/beta optional).  stat_is_var: `rstd` holds a variance
+// (inference BatchNorm with running statistics) and eps is applied here.
+template <int VEC>
+__global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x, int ldx,
+                                                    float* __restrict__ y, int ldy, unsigned G,
+                                                    unsigned R, unsigned C,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int stat_is_var,
+                                                    float eps) {
+  const unsigned CQ = C / VEC;
+  const unsigned total = G * R * CQ;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / CQ, cq = idx - row * CQ;
+    const unsigned g = row / R;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const unsigned c = cq * VEC + i;
+      float rs = rstd[(size_t)g * C + c];
+      if (stat_is_var) rs = 1.0f / sqrtf(rs + eps);
+      float v = (x[(size_t)row * ldx + c] - mean[(size_t)g * C + c]) * rs;
+      if (gamma) v = v * gamma[c] + beta[c];
+      y[(size_t)row * ldy + c] = v;
+    }
+  }
+}
+
+// Backward partial sums per (g, chunk, c): s1 = sum dy, s2 = sum dy * xhat.   part: [G][nchunk][2][C]
+__global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ dy, int lddy,
+                                                          unsigned R, unsigned C, unsigned chunk,
+                                                          unsigned nchunk,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          float* __restrict__ part) {
+  __shared__ float r1s[256], r2s[256];
+  const unsigned CPB = C >= 256 ? 256 : C;
+  const unsigned RL = 256 / CPB;
+  const unsigned tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
+  const unsigned col = blockIdx.y * CPB + tx;
+  const unsigned g = blockIdx.z;
+  const unsigned r0 = blockIdx.x * chunk;
+  unsigned r1 = r0 + chunk;
+  if (r1 > R) r1 = R;
+  float s1 = 0.f, s2 = 0.f;
+  if (ty < RL && col < C) {
+    const float mu = mean[(size_t)g * C + col], rs = rstd[(size_t)g * C + col];
+    const float* bx = x + (size_t)g * R * ldx;
+    const float* bd = dy + (size_t)g * R * lddy;
+    for (unsigned r = r0 + ty; r < r1; r += RL) {
+      const float d = bd[(size_t)r * lddy + col];
+      const float xh = (bx[(size_t)r * ldx + col] - mu) * rs;
+      s1 += d;
+      s2 += d * xh;
+    }
+  }
+  r1s[threadIdx.x] = s1; r2s[threadIdx.x] = s2;
+  __syncthreads();
+  if (ty == 0 && col < C) {
+    float a = 0.f, b = 0.f;
+    for (unsigned l = 0; l < RL; ++l) { a += r1s[l * CPB + tx]; b += r2s[l * CPB + tx]; }
+    float* o = part + ((size_t)g * nchunk + blockIdx.x) * 2 * C;
+    o[col] = a; o[C + col] = b;
+  }
+}
+
+// sums[g][2][C]; optional dgamma/dbeta (BatchNorm: G == 1) with accumulate flag.
+__global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict__ part,
+                                                        unsigned nchunk, unsigned C,
+                                                        float* __restrict__ sums,
+                                                        float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta) {
+  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  const unsigned g = blockIdx.y;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (unsigned k = 0; k < nchunk; ++k) {
+    const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
+    a += o[c]; b += o[C + c];
+  }
+  sums[(size_t)g * 2 * C + c] = a;
+  sums[(size_t)g * 2 * C + C + c] = b;
+  if (dgamma) { dgamma[c] = b; dbeta[c] = a; }
+}
+
+// dx = rstd * gamma * (dy - s1/R - xhat * s2/R)
+template <int VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ dy, int lddy,
+                                                        float* __restrict__ dx, int lddx, unsigned G,
+                                                        unsigned R, unsigned C,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ sums) {
+  const unsigned CQ = C / VEC;
+  const unsigned total = G * R * CQ;
+  const float invR = 1.0f / (float)R;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / CQ, cq = idx - row * CQ;
+    const unsigned g = row / R;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const unsigned c = cq * VEC + i;
+      const float mu = mean[(size_t)g * C + c], rs = rstd[(size_t)g * C + c];
+      const float xh = (x[(size_t)row * ldx + c] - mu) * rs;
+      const float s1 = sums[(size_t)g * 2 * C + c], s2 = sums[(size_t)g * 2 * C + C + c];
+      float v = dy[(size_t)row * lddy + c] - s1 * invR - xh * s2 * invR;
+      v *= rs;
+      if (gamma) v *= gamma[c];
+      dx[(size_t)row * lddx + c] = v;
+    }
+  }
+}
+
+// inference BatchNorm backward is never needed on the hot path (test_step runs without grad).
+
+inline int grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline void chunking(long long R, int C, unsigned& chunk, unsigned& nchunk) {
+  const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
+  const unsigned RL = 256 / CPB;
+  chunk = EPT * RL;
+  nchunk = (unsigned)((R + chunk - 1) / chunk);
+}
+
+}  // namespace
+
+extern "C" {
+
+long long so_norm_ws_floats(int G, long long R, int C) {
+  unsigned chunk, nchunk;
+  chunking(R, C, chunk, nchunk);
+  return (long long)G * nchunk * 3 * C + (long long)G * 2 * C;
+}
+
+// Training-mode statistics + normalisation.  mean/rstd: [G][C] outputs (saved for backward).
+int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
+                const float* gamma, const float* beta, float* mean, float* rstd,
+                float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
+  if (G <= 0 || R <= 0 || C <= 0) return 0;
+  if (running_mean && G != 1) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned chunk, nchunk;
+  chunking(R, C, chunk, nchunk);
+  const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
+  dim3 g1(nchunk, so_cdiv(C, CPB), G);
+  hipLaunchKernelGGL(stats_partial_k, g1, dim3(256), 0, st, x, ldx, (unsigned)R, (unsigned)C, chunk,
+                     nchunk, ws);
+  dim3 g2(so_cdiv(C, 256), G);
+  hipLaunchKernelGGL(stats_final_k, g2, dim3(256), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
+                     running_mean, running_var, momentum);
+  const long long total = (long long)G * R * C;
+  if ((C & 3) == 0)
+    hipLaunchKernelGGL(norm_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y, ldy,
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps);
+  else
+    hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, y, ldy,
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps);
+  return SO_LAUNCH_CHECK();
+}
+
+// Inference-mode normalisation with given statistics (BatchNorm eval: mean = running_mean,
+// var = running_var, stat_is_var = 1).
+int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R, int C,
+                  const float* mean, const float* stat, int stat_is_var, float eps,
+                  const float* gamma, const float* beta, void* stream) {
+  if (G <= 0 || R <= 0 || C <= 0) return 0;
+  const long long total = (long long)G * R * C;
+  hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     y, ldy, (unsigned)G, (unsigned)R, (unsigned)C, mean, stat, gamma, beta,
+                     stat_is_var, eps);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                float* dgamma, float* dbeta, float* ws, void* stream) {
+  if (G <= 0 || R <= 0 || C <= 0) return 0;
+  if (dgamma && G != 1) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned chunk, nchunk;
+  chunking(R, C, chunk, nchunk);
+  const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
+  float* part = ws;
+  float* sums = ws + (size_t)G * nchunk * 3 * C;
+  dim3 g1(nchunk, so_cdiv(C, CPB), G);
+  hipLaunchKernelGGL(norm_bwd_partial_k, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
+                     (unsigned)C, chunk, nchunk, mean, rstd, part);
+  dim3 g2(so_cdiv(C, 256), G);
+  hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(256), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
+                     dbeta);
+  const long long total = (long long)G * R * C;
+  if ((C & 3) == 0)
+    hipLaunchKernelGGL(norm_bwd_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,
+                       lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums);
+  else
+    hipLaunchKernelGGL(norm_bwd_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, dy, lddy,
+                       dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums);
+  return SO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""U-Net generator of the try-on module (reference: models/networks/cpvton/unet.py:9-211).
+
+Same constructor signatures and the same nn.Sequential layout as the reference (so checkpoints drop
+in); down-steps are Conv4x4/s2, up-steps are activation -> bilinear x2 -> Conv3x3 -> norm, attention is
+spent from the innermost block outwards with one SelfAttention on the down side and one on the up side
+of every attended block.
+"""
+from torch import nn
+
+from ... import ops
+from ..attention.sagan import SelfAttention
+from ..layers import (HipConv2d, HipGELU, HipInstanceNorm2d, HipBatchNorm2d, HipLeakyReLU, HipReLU, HipUpsample2x,
+                      Sine, Swish)
+
+_NORMS = {"instance": HipInstanceNorm2d, "batch": HipBatchNorm2d}
+
+
+def _resolve_norm(norm_layer):
+    """Accept our own classes, the names 'instance'/'batch', or the torch classes the reference passes."""
+    if norm_layer in (HipInstanceNorm2d, HipBatchNorm2d):
+        return norm_layer
+    if isinstance(norm_layer, str):
+        return _NORMS[norm_layer]
+    if norm_layer is nn.InstanceNorm2d:
+        return HipInstanceNorm2d
+    if norm_layer is nn.BatchNorm2d:
+        return HipBatchNorm2d
+    raise ValueError(f"unsupported norm_layer {norm_layer}")
+
+
+class UnetGenerator(nn.Module):
+    def __init__(self, input_nc, output_nc, num_downs, num_attention, ngf=64, norm_layer=HipBatchNorm2d,
+                 use_dropout=False, use_self_attn=False, activation=None):
+        super().__init__()
+        if use_dropout:
+            raise NotImplementedError("use_dropout is never enabled on the reference's hot path")
+
+        def attn():
+            return use_self_attn if use_self_attn and num_attention > 0 else None
+
+        block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=None, norm_layer=norm_layer, innermost=True,
+                                        self_attn=attn(), activation=activation)
+        num_attention -= 1
+        for _ in range(num_downs - 5):
+            block = UnetSkipConnectionBlock(ngf * 8, ngf * 8, submodule=block, norm_layer=norm_layer,
+                                            self_attn=attn(), activation=activation)
+            num_attention -= 1
+        for outer, inner in ((ngf * 4, ngf * 8), (ngf * 2, ngf * 4), (ngf, ngf * 2)):
+            block = UnetSkipConnectionBlock(outer, inner, submodule=block, norm_layer=norm_layer,
+                                            self_attn=attn(), activation=activation)
+            num_attention -= 1
+        block = UnetSkipConnectionBlock(output_nc, ngf, input_nc=input_nc, submodule=block, outermost=True,
+                                        norm_layer=norm_layer, self_attn=attn(), activation=activation)
+        self.model = block
+
+    def forward(self, input):
+        return self.model(input)
+
+
+class UnetSkipConnectionBlock(nn.Module):
+    """X ---------------- identity ---------------- X
+         |-- downsampling -- |submodule| -- upsampling --|"""
+
+    def __init__(self, outer_nc, inner_nc, input_nc=None, submodule=None, outermost=False, innermost=False,
+                 norm_layer=HipBatchNorm2d, self_attn=False, use_dropout=False, activation=None):
+        super().__init__()
+        norm_layer = _resolve_norm(norm_layer)
+        self.outermost = outermost
+        use_bias = norm_layer is HipInstanceNorm2d
+        if input_nc is None:
+            input_nc = outer_nc
+        downconv = HipConv2d(input_nc, inner_nc, kernel_size=4, stride=2, padding=1, bias=use_bias)
+        down_activation = HipLeakyReLU(0.2) if activation is None else _get_activation_fn(activation)
+        downnorm = norm_layer(inner_nc)
+        up_activation = HipReLU() if activation is None else _get_activation_fn(activation)
+        upnorm = norm_layer(outer_nc)
+        # The reference's default down activation is LeakyReLU(0.2, inplace=True): it overwrites the block
+        # input before the skip concatenation, so the skip carries leaky_relu(x).
+        self.skip_carries_activation = activation is None and not outermost
+        up_in = inner_nc if innermost else inner_nc * 2
+        upconv = HipConv2d(up_in, outer_nc, kernel_size=3, stride=1, padding=1, bias=use_bias)
+        if outermost:
+            down = [downconv]
+        elif innermost:
+            down = [down_activation, downconv]
+        else:
+            down = [down_activation, downconv, downnorm]
+        up = [up_activation, HipUpsample2x(), upconv, upnorm]
+        if self_attn:
+            down.append(SelfAttention(inner_nc, "relu"))
+            up.append(SelfAttention(outer_nc, "relu"))
+        model = down + ([] if innermost else [submodule]) + up
+        self.model = nn.Sequential(*model)
+
+    def forward(self, x):
+        if self.outermost:
+            return self.model(x)
+        mods = list(self.model)
+        if self.skip_carries_activation:
+            x = mods[0](x)
+            mods = mods[1:]
+        h = x
+        for m in mods:
+            h = m(h)
+        return ops.cat_channels([x, h])
+
+
+def _get_activation_fn(activation):
+    if activation == "relu":
+        return HipReLU()
+    if activation == "gelu":
+        return HipGELU()
+    if activation == "swish":
+        return Swish()
+    if activation == "sine":
+        return Sine()
+    raise RuntimeError(f"The selected activation should be relu/gelu/swish/sine, not {activation}")

@@ -1,0 +1,156 @@
+"""nn.Module shells around the HIP operators.
+
+They exist so that the module TREE (attribute names, nn.Sequential indices) — and therefore every
+`state_dict` key and tensor shape — is identical to the reference's, while the
+arithmetic runs in libshineon_hip.so.  Class names keep the substrings `Conv`, `Linear`,
+`BatchNorm2d` because the reference's `weights_init_normal` dispatches on them
+(models/networks/__init__.py:52-60).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import ops
+
+
+def _ohwi_param(o, i, r, s):
+    """(O, I, R, S) parameter whose memory is OHWI (what the MFMA loaders read in place)."""
+    return nn.Parameter(torch.empty(o, r, s, i).permute(0, 3, 1, 2))
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d(in, out, k, stride, padding, bias) replacement (zero padding, dilation 1, groups 1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, fuse_relu=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.fuse_relu = fuse_relu
+        self.weight = _ohwi_param(out_channels, in_channels, kernel_size, kernel_size)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # PyTorch's default Conv2d init (torch/nn/modules/conv.py): the reference keeps it for biases
+        # everywhere and for all FeatureRegression weights.
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size * self.kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding,
+                          ops.ACT_RELU if self.fuse_relu else ops.ACT_NONE)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, bias={self.bias is not None}, fuse_relu={self.fuse_relu}")
+
+
+class HipInstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(C) with its defaults: affine=False, track_running_stats=False, eps=1e-5."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+
+    def forward(self, x):
+        return ops.instance_norm(x, self.eps)
+
+
+class HipBatchNorm2d(nn.Module):
+    """nn.BatchNorm2d(C): batch statistics in training (running stats updated with momentum 0.1 and the
+    unbiased variance), running statistics in eval."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        if self.training:
+            self.num_batches_tracked += 1
+            return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                        self.momentum, self.eps)
+        return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)
+
+
+class HipLinearCHW(nn.Module):
+    """nn.Linear applied to `x.view(N, -1)` of an (N, C, H, W) map, optionally followed by tanh.
+    The weight keeps the reference's (C, H, W) flatten order (warp.py:87,95-97)."""
+
+    def __init__(self, in_features, out_features, apply_tanh=False):
+        super().__init__()
+        self.in_features, self.out_features, self.apply_tanh = in_features, out_features, apply_tanh
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.linear_chw_tanh(x, self.weight, self.bias, self.apply_tanh)
+
+
+class HipActivation(nn.Module):
+    def __init__(self, kind, param=0.0):
+        super().__init__()
+        self.kind, self.param = kind, param
+
+    def forward(self, x):
+        return ops.activation(x, self.kind, self.param)
+
+    def extra_repr(self):
+        return f"{self.kind}" + (f", {self.param}" if self.param else "")
+
+
+class HipLeakyReLU(HipActivation):
+    def __init__(self, negative_slope=0.2):
+        super().__init__("leaky", negative_slope)
+
+
+class HipReLU(HipActivation):
+    def __init__(self):
+        super().__init__("relu")
+
+
+class HipGELU(HipActivation):
+    def __init__(self):
+        super().__init__("gelu")
+
+
+class Swish(HipActivation):
+    def __init__(self):
+        super().__init__("swish")
+
+
+class Sine(HipActivation):
+    def __init__(self):
+        super().__init__("sine")
+
+
+class FusedReLU(nn.Module):
+    """Placeholder keeping the nn.Sequential index of a ReLU whose work is fused in the preceding
+    convolution's epilogue (VGG19 slices)."""
+
+    def forward(self, x):
+        return x
+
+
+class HipUpsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode="bilinear") (align_corners=False)."""
+
+    def forward(self, x):
+        return ops.upsample2x_bilinear(x)
+
+
+class HipMaxPool2x2(nn.Module):
+    def forward(self, x):
+        return ops.maxpool2x2(x)

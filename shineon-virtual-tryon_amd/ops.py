@@ -1,0 +1,932 @@
+"""Autograd operators of the try-on hot path, each one a thin host wrapper around the C ABI
+(include/shineon_hip.h).  torch is used for device memory (torch.empty), the current stream and the
+autograd tape only; every FLOP and every byte moved on the hot path goes through libshineon_hip.so.
+
+Layout contract: a 4-D activation is a torch tensor of logical shape (N, C, H, W) whose strides are
+NHWC-with-pitch: (H*W*ld, 1, W*ld, ld), ld >= C.  That is exactly torch's channels_last when ld == C,
+and a channel slice of a wider NHWC buffer when ld > C, so the reference's NCHW-shaped module
+interfaces are kept while the kernels see "pixel rows x channel columns".
+"""
+import math
+
+import torch
+
+from ._lib import check, lib
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_GELU, ACT_SWISH, ACT_SINE, ACT_TANH, ACT_SIGMOID = range(8)
+ACT_CODES = {
+    None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "leaky": ACT_LEAKY, "gelu": ACT_GELU,
+    "swish": ACT_SWISH, "sine": ACT_SINE, "tanh": ACT_TANH, "sigmoid": ACT_SIGMOID,
+}
+
+_WS = {}
+_WS_BYTES = 256 << 20
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "shineon_amd ops run on an MI355X only (got a CPU tensor); there is no CPU fallback. "
+            "Use oracle/ for a CPU check."
+        )
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device, min_bytes=0):
+    """Per-device scratch slab (split-K slabs, reduction partials)."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    need = max(_WS_BYTES, int(min_bytes))
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def nhwc_empty(n, h, w, c, device, ld=None):
+    """(N, C, H, W)-shaped view over a fresh [N][H][W][ld] buffer."""
+    ld = c if ld is None else ld
+    buf = torch.empty((n, h, w, ld), dtype=torch.float32, device=device)
+    t = buf.permute(0, 3, 1, 2)
+    return t if ld == c else t[:, :c]
+
+
+def _is_rows(t):
+    if t.dim() != 4 or t.dtype != torch.float32:
+        return False
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return False
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    if ld < c:
+        return False
+    if w > 1 and sw != ld:
+        return False
+    if h > 1 and sh != w * ld:
+        return False
+    if n > 1 and sn != h * w * ld:
+        return False
+    return True
+
+
+def _ld(t):
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if w > 1:
+        return sw
+    if h > 1:
+        return sh
+    if n > 1:
+        return sn
+    return c
+
+
+def to_rows(t, cpad=None):
+    """Return a tensor in the NHWC-with-pitch layout (converting with our own kernels if needed).
+    cpad: produce a fresh buffer whose channel count is zero-padded up to cpad."""
+    _require_cuda(t)
+    if t.dtype != torch.float32:
+        raise TypeError("fp32 only")
+    n, c, h, w = t.shape
+    L = lib()
+    if cpad is None or cpad == c:
+        if _is_rows(t):
+            return t
+        cd = c
+    else:
+        cd = cpad
+    out = nhwc_empty(n, h, w, cd, t.device)
+    if _is_rows(t):
+        check(L.so_copy2d(t.data_ptr(), _ld(t), c, out.data_ptr(), cd, cd, n * h * w, 0, _stream()), "copy2d")
+    else:
+        src = t if t.is_contiguous() else t.contiguous()
+        check(L.so_nchw_to_nhwc(src.data_ptr(), out.data_ptr(), cd, n, c, cd, h * w, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def to_nchw(t):
+    """Planar NCHW copy of an NHWC-pitch tensor (boundary conversion for PNG writers / visualisation)."""
+    _require_cuda(t)
+    if t.is_contiguous():
+        return t
+    t = to_rows(t)
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=t.device)
+    check(lib().so_nhwc_to_nchw(t.data_ptr(), _ld(t), out.data_ptr(), n, c, h * w, _stream()), "nhwc_to_nchw")
+    return out
+
+
+def _aligned(t, ld):
+    return (t.data_ptr() % 16 == 0) and (ld % 4 == 0)
+
+
+def _dense_rows(t):
+    """rows layout AND 16-byte aligned / pitch % 4 == 0 (what the MFMA loaders need)."""
+    t = to_rows(t)
+    if not _aligned(t, _ld(t)) or t.shape[1] % 4:
+        c = t.shape[1]
+        t = to_rows(t, cpad=(c + 3) // 4 * 4) if c % 4 else _copy_rows(t)
+    return t
+
+
+def _copy_rows(t):
+    n, c, h, w = t.shape
+    out = nhwc_empty(n, h, w, c, t.device)
+    check(lib().so_copy2d(t.data_ptr(), _ld(t), c, out.data_ptr(), c, c, n * h * w, 0, _stream()), "copy2d")
+    return out
+
+
+def _ohwi(weight, cpad=None):
+    """Weight (O, I, R, S) -> dense OHWI memory [O][R][S][Ipad] as an (O, R, S, Ipad) tensor."""
+    o, i, r, s = weight.shape
+    w = weight.detach()
+    cp = i if cpad is None else cpad
+    L = lib()
+    ohwi_view = w.permute(0, 2, 3, 1)
+    if ohwi_view.is_contiguous():
+        if cp == i:
+            return ohwi_view
+        out = torch.empty((o, r, s, cp), dtype=torch.float32, device=w.device)
+        check(L.so_copy2d(w.data_ptr(), i, i, out.data_ptr(), cp, cp, o * r * s, 0, _stream()), "copy2d")
+        return out
+    src = w if w.is_contiguous() else w.contiguous()
+    out = torch.empty((o, r, s, cp), dtype=torch.float32, device=w.device)
+    check(L.so_nchw_to_nhwc(src.data_ptr(), out.data_ptr(), cp, o, i, cp, r * s, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def _colsum(t2d_ptr, ld, rows, c, device):
+    L = lib()
+    out = torch.empty(c, dtype=torch.float32, device=device)
+    need = L.so_colsum_ws_floats(rows, c) * 4
+    ws = workspace(device, need)
+    check(L.so_colsum(t2d_ptr, ld, rows, c, out.data_ptr(), 0, ws.data_ptr(), _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv2d
+# ------------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        L = lib()
+        o, i, r, s = weight.shape
+        cp = (i + 3) // 4 * 4
+        xr = to_rows(x, cpad=cp) if cp != i else _dense_rows(x)
+        w = _ohwi(weight, cpad=cp)
+        n, _, h, wd = xr.shape
+        ho = (h + 2 * pad - r) // stride + 1
+        wo = (wd + 2 * pad - s) // stride + 1
+        y = nhwc_empty(n, ho, wo, o, x.device)
+        ws = workspace(x.device)
+        check(
+            L.so_conv2d_fprop(
+                xr.data_ptr(), _ld(xr), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                y.data_ptr(), o, n, h, wd, cp, o, r, s, stride, pad, act, 0.0,
+                ws.data_ptr(), ws.numel() * 4, _stream(),
+            ),
+            "conv2d_fprop",
+        )
+        ctx.save_for_backward(xr, w, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, i, cp, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        xr, w, y = ctx.saved_tensors
+        stride, pad, act, i, cp, has_bias, wshape = ctx.cfg
+        o, _, r, s = wshape
+        n, _, h, wd = xr.shape
+        dy = _dense_rows(dy)
+        dev = dy.device
+        rows_out = dy.shape[0] * dy.shape[2] * dy.shape[3]
+        if act != ACT_NONE:
+            g = nhwc_empty(dy.shape[0], dy.shape[2], dy.shape[3], o, dev)
+            check(L.so_act_bwd(y.data_ptr(), _ld(y), dy.data_ptr(), _ld(dy), g.data_ptr(), o, rows_out, o, act, 0.0, _stream()), "act_bwd")
+            dy = g
+        ws = workspace(dev)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxp = nhwc_empty(n, h, wd, cp, dev)
+            check(
+                L.so_conv2d_dgrad(dy.data_ptr(), _ld(dy), w.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, o, r, s,
+                                  stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                "conv2d_dgrad",
+            )
+            dx = dxp if cp == i else dxp[:, :i]
+        if ctx.needs_input_grad[1]:
+            dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
+            check(
+                L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
+                                  stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                "conv2d_wgrad",
+            )
+            if cp != i:
+                dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
+                check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
+                dwp = dwd
+            dw = dwp.permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE):
+    """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA."""
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act)
+
+
+# ------------------------------------------------------------------------------------------------
+# pointwise
+# ------------------------------------------------------------------------------------------------
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, param):
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, h, w, c, x.device)
+        check(lib().so_act_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, n * h * w, c, act, param, _stream()), "act_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, param)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        act, param = ctx.cfg
+        dy = to_rows(dy)
+        n, c, h, w = x.shape
+        dx = nhwc_empty(n, h, w, c, x.device)
+        check(lib().so_act_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n * h * w, c, act, param, _stream()), "act_bwd")
+        return dx, None, None
+
+
+def activation(x, kind, param=0.0):
+    return _ActFn.apply(x, ACT_CODES[kind] if not isinstance(kind, int) else kind, float(param))
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        L = lib()
+        xs = [to_rows(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        ct = sum(cs)
+        out = nhwc_empty(n, h, w, ct, xs[0].device)
+        off = 0
+        for x, c in zip(xs, cs):
+            check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * off, ct, c, n * h * w, 0, _stream()), "copy2d")
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_rows(dy)
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    """torch.cat(xs, dim=1) for NHWC-pitch tensors (gradient = channel slices, no copy)."""
+    return _CatFn.apply(*xs)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, 2 * h, 2 * w, c, x.device)
+        check(lib().so_upsample2x_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, n, h, w, c, _stream()), "upsample2x_fwd")
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = to_rows(dy)
+        dx = nhwc_empty(n, h, w, c, dy.device)
+        check(lib().so_upsample2x_bwd(dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, _stream()), "upsample2x_bwd")
+        return dx
+
+
+def upsample2x_bilinear(x):
+    return _Upsample2xFn.apply(x)
+
+
+class _MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, h // 2, w // 2, c, x.device)
+        check(lib().so_maxpool2_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, n, h, w, c, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = to_rows(dy)
+        dx = nhwc_empty(n, h, w, c, x.device)
+        check(lib().so_maxpool2_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, _stream()), "maxpool2_bwd")
+        return dx
+
+
+def maxpool2x2(x):
+    return _MaxPool2Fn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+class _NormFn(torch.autograd.Function):
+    """InstanceNorm2d (instance=True) or BatchNorm2d training (instance=False)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps):
+        L = lib()
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        G, R = (n, h * w) if instance else (1, n * h * w)
+        y = nhwc_empty(n, h, w, c, x.device)
+        mean = torch.empty((G, c), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((G, c), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
+        check(
+            L.so_norm_fwd(
+                x.data_ptr(), _ld(x), y.data_ptr(), c, G, R, c, eps,
+                gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None,
+                mean.data_ptr(), rstd.data_ptr(),
+                running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None,
+                momentum, ws.data_ptr(), _stream(),
+            ),
+            "norm_fwd",
+        )
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.cfg = (G, R)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        x, mean, rstd, gamma = ctx.saved_tensors
+        G, R = ctx.cfg
+        n, c, h, w = x.shape
+        dy = to_rows(dy)
+        dx = nhwc_empty(n, h, w, c, x.device)
+        dgamma = dbeta = None
+        if gamma is not None:
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
+        check(
+            L.so_norm_bwd(
+                x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
+                gamma.data_ptr() if gamma is not None else None,
+                dgamma.data_ptr() if dgamma is not None else None, dbeta.data_ptr() if dbeta is not None else None,
+                ws.data_ptr(), _stream(),
+            ),
+            "norm_bwd",
+        )
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def instance_norm(x, eps=1e-5):
+    return _NormFn.apply(x, None, None, None, None, True, 0.0, eps)
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    return _NormFn.apply(x, gamma, beta, running_mean, running_var, False, momentum, eps)
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    x = to_rows(x)
+    n, c, h, w = x.shape
+    y = nhwc_empty(n, h, w, c, x.device)
+    check(
+        lib().so_norm_apply(x.data_ptr(), _ld(x), y.data_ptr(), c, 1, n * h * w, c, running_mean.data_ptr(),
+                            running_var.data_ptr(), 1, eps, gamma.data_ptr(), beta.data_ptr(), _stream()),
+        "norm_apply",
+    )
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# SAGAN self-attention (models/networks/attention/sagan.py:29-54)
+# ------------------------------------------------------------------------------------------------
+def _gemm(ta, tb, M, N, K, A, lda, sa, B, ldb, sb, C, ldc, sc, batch, alpha=None, bias=None, res=None, ldres=0, sres=0,
+          act=ACT_NONE, device=None):
+    ws = workspace(device)
+    check(
+        lib().so_gemm_batched(
+            ta, tb, M, N, K, A, lda, sa, B, ldb, sb, C, ldc, sc, batch,
+            alpha, bias, res, ldres, sres, act, 0.0, ws.data_ptr(), ws.numel() * 4, _stream(),
+        ),
+        "gemm_batched",
+    )
+
+
+class _SelfAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        L = lib()
+        x = _dense_rows(x)
+        b, c, h, w = x.shape
+        n = h * w
+        d = wq.shape[0]
+        dev = x.device
+        if c % 4 or d % 4 or n % 4:
+            raise RuntimeError("self-attention kernels need C, C//8 and H*W to be multiples of 4")
+        wq2, wk2, wv2 = (_ohwi(t).reshape(t.shape[0], c) for t in (wq, wk, wv))
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        q, k, v = f(b * n, d), f(b * n, d), f(b * n, c)
+        ldx = _ld(x)
+        xp = x.data_ptr()
+        # 1x1 convolutions: rows x C  @  W^T  (+ bias)
+        _gemm(0, 1, b * n, d, c, xp, ldx, 0, wq2.data_ptr(), c, 0, q.data_ptr(), d, 0, 1, bias=bq.data_ptr(), device=dev)
+        _gemm(0, 1, b * n, d, c, xp, ldx, 0, wk2.data_ptr(), c, 0, k.data_ptr(), d, 0, 1, bias=bk.data_ptr(), device=dev)
+        _gemm(0, 1, b * n, c, c, xp, ldx, 0, wv2.data_ptr(), c, 0, v.data_ptr(), c, 0, 1, bias=bv.data_ptr(), device=dev)
+        # energy[b] = q[b] k[b]^T ; attention = softmax(rows)
+        e = f(b * n, n)
+        _gemm(0, 1, n, n, d, q.data_ptr(), d, n * d, k.data_ptr(), d, n * d, e.data_ptr(), n, n * n, b, device=dev)
+        a = f(b * n, n)
+        check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
+        # o[b] = attention[b] v[b] ; out = gamma * o + x
+        o = f(b * n, c)
+        _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, v.data_ptr(), c, n * c, o.data_ptr(), c, n * c, b, device=dev)
+        out = nhwc_empty(b, h, w, c, dev)
+        check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
+        ctx.save_for_backward(x, wq2, wk2, wv2, q, k, v, a, o, gamma)
+        ctx.shapes = (tuple(wq.shape), tuple(wk.shape), tuple(wv.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = lib()
+        x, wq2, wk2, wv2, q, k, v, a, o, gamma = ctx.saved_tensors
+        b, c, h, w = x.shape
+        n = h * w
+        d = wq2.shape[0]
+        dev = x.device
+        dout = _dense_rows(dout)
+        ldg = _ld(dout)
+        gp = dout.data_ptr()
+        f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        ws = workspace(dev)
+        # d gamma = <dout, o>
+        dgamma = f(1)
+        check(L.so_dot(gp, ldg, o.data_ptr(), c, b * n, c, 1.0, dgamma.data_ptr(), ws.data_ptr(), _stream()), "dot")
+        gm = gamma.data_ptr()
+        # dv[b] = gamma * a[b]^T dout[b] ; da[b] = gamma * dout[b] v[b]^T
+        dv = f(b * n, c)
+        _gemm(1, 0, n, c, n, a.data_ptr(), n, n * n, gp, ldg, n * ldg, dv.data_ptr(), c, n * c, b, alpha=gm, device=dev)
+        da = f(b * n, n)
+        _gemm(0, 1, n, n, c, gp, ldg, n * ldg, v.data_ptr(), c, n * c, da.data_ptr(), n, n * n, b, alpha=gm, device=dev)
+        de = f(b * n, n)
+        check(L.so_softmax_rows_bwd(a.data_ptr(), n, da.data_ptr(), n, de.data_ptr(), n, b * n, n, _stream()), "softmax_bwd")
+        # dq[b] = de[b] k[b] ; dk[b] = de[b]^T q[b]
+        dq, dk = f(b * n, d), f(b * n, d)
+        _gemm(0, 0, n, d, n, de.data_ptr(), n, n * n, k.data_ptr(), d, n * d, dq.data_ptr(), d, n * d, b, device=dev)
+        _gemm(1, 0, n, d, n, de.data_ptr(), n, n * n, q.data_ptr(), d, n * d, dk.data_ptr(), d, n * d, b, device=dev)
+        # dx = dout + dq Wq + dk Wk + dv Wv   (1x1-conv input gradients chained through the residual epilogue)
+        dx = nhwc_empty(b, h, w, c, dev)
+        dxp = dx.data_ptr()
+        _gemm(0, 0, b * n, c, d, dq.data_ptr(), d, 0, wq2.data_ptr(), c, 0, dxp, c, 0, 1, res=gp, ldres=ldg, device=dev)
+        _gemm(0, 0, b * n, c, d, dk.data_ptr(), d, 0, wk2.data_ptr(), c, 0, dxp, c, 0, 1, res=dxp, ldres=c, device=dev)
+        _gemm(0, 0, b * n, c, c, dv.data_ptr(), c, 0, wv2.data_ptr(), c, 0, dxp, c, 0, 1, res=dxp, ldres=c, device=dev)
+        # weight / bias gradients: dW = dY^T X
+        xp, ldx = x.data_ptr(), _ld(x)
+        dwq, dwk, dwv = f(d, c), f(d, c), f(c, c)
+        _gemm(1, 0, d, c, b * n, dq.data_ptr(), d, 0, xp, ldx, 0, dwq.data_ptr(), c, 0, 1, device=dev)
+        _gemm(1, 0, d, c, b * n, dk.data_ptr(), d, 0, xp, ldx, 0, dwk.data_ptr(), c, 0, 1, device=dev)
+        _gemm(1, 0, c, c, b * n, dv.data_ptr(), c, 0, xp, ldx, 0, dwv.data_ptr(), c, 0, 1, device=dev)
+        dbq = _colsum(dq.data_ptr(), d, b * n, d, dev)
+        dbk = _colsum(dk.data_ptr(), d, b * n, d, dev)
+        dbv = _colsum(dv.data_ptr(), c, b * n, c, dev)
+        sq, sk, sv = ctx.shapes
+        return dx, dwq.view(sq), dbq, dwk.view(sk), dbk, dwv.view(sv), dbv, dgamma
+
+
+def self_attention(x, wq, bq, wk, bk, wv, bv, gamma):
+    return _SelfAttentionFn.apply(x, wq, bq, wk, bk, wv, bv, gamma)
+
+
+# ------------------------------------------------------------------------------------------------
+# GMM pieces
+# ------------------------------------------------------------------------------------------------
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, transpose_hw):
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        y = nhwc_empty(n, w, h, c, x.device) if transpose_hw else nhwc_empty(n, h, w, c, x.device)
+        inv = torch.empty(n * h * w, dtype=torch.float32, device=x.device)
+        check(lib().so_l2norm_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, inv.data_ptr(), n, h, w, c, int(transpose_hw), _stream()), "l2norm_fwd")
+        ctx.save_for_backward(y, inv)
+        ctx.cfg = (n, c, h, w, transpose_hw)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        n, c, h, w, tr = ctx.cfg
+        dy = to_rows(dy)
+        dx = nhwc_empty(n, h, w, c, y.device)
+        check(lib().so_l2norm_bwd(y.data_ptr(), c, dy.data_ptr(), _ld(dy), inv.data_ptr(), dx.data_ptr(), c, n, h, w, c, int(tr), _stream()), "l2norm_bwd")
+        return dx, None
+
+
+def feature_l2norm(x, transpose_hw=False):
+    """FeatureL2Norm; transpose_hw=True additionally returns the (N, C, W, H) transposed map that
+    FeatureCorrelation builds from feature A (warp.py:60)."""
+    return _L2NormFn.apply(x, transpose_hw)
+
+
+class _CorrelationFn(torch.autograd.Function):
+    """corr[b, ja*h+ia, i, j] = sum_c A[b,c,ia,ja] B[b,c,i,j]; `a_t` is A already transposed to (N,C,W,H)."""
+
+    @staticmethod
+    def forward(ctx, a_t, fb):
+        a_t, fb = _dense_rows(a_t), _dense_rows(fb)
+        b, c, h, w = fb.shape
+        n = h * w
+        out = nhwc_empty(b, h, w, n, fb.device)
+        _gemm(0, 1, n, n, c, fb.data_ptr(), _ld(fb), n * _ld(fb), a_t.data_ptr(), _ld(a_t), n * _ld(a_t),
+              out.data_ptr(), n, n * n, b, device=fb.device)
+        ctx.save_for_backward(a_t, fb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a_t, fb = ctx.saved_tensors
+        b, c, h, w = fb.shape
+        n = h * w
+        dy = _dense_rows(dy)
+        ldg = _ld(dy)
+        dev = fb.device
+        dfb = nhwc_empty(b, h, w, c, dev)
+        da = nhwc_empty(b, w, h, c, dev)
+        # dB[b] = dcorr[b] A_t[b]   ;   dA_t[b] = dcorr[b]^T B[b]
+        _gemm(0, 0, n, c, n, dy.data_ptr(), ldg, n * ldg, a_t.data_ptr(), _ld(a_t), n * _ld(a_t), dfb.data_ptr(), c, n * c, b, device=dev)
+        _gemm(1, 0, n, c, n, dy.data_ptr(), ldg, n * ldg, fb.data_ptr(), _ld(fb), n * _ld(fb), da.data_ptr(), c, n * c, b, device=dev)
+        return da, dfb
+
+
+def feature_correlation(a_transposed, fb):
+    return _CorrelationFn.apply(a_transposed, fb)
+
+
+class _LinearTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, apply_tanh):
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        j = weight.shape[0]
+        wt = weight.detach().contiguous()
+        y = torch.empty((n, j), dtype=torch.float32, device=x.device)
+        check(lib().so_linear_chw_fwd(x.data_ptr(), _ld(x), wt.data_ptr(), bias.data_ptr(), y.data_ptr(), n, h * w, c, j, int(apply_tanh), _stream()), "linear_fwd")
+        ctx.save_for_backward(x, wt, y)
+        ctx.apply_tanh = apply_tanh
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt, y = ctx.saved_tensors
+        n, c, h, w = x.shape
+        j = wt.shape[0]
+        dy = dy.contiguous()
+        dx = nhwc_empty(n, h, w, c, x.device) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wt)
+        db = torch.empty(j, dtype=torch.float32, device=x.device)
+        check(
+            lib().so_linear_chw_bwd(x.data_ptr(), _ld(x), wt.data_ptr(), y.data_ptr(), dy.data_ptr(),
+                                    dx.data_ptr() if dx is not None else None, c, dw.data_ptr(), db.data_ptr(),
+                                    n, h * w, c, j, int(ctx.apply_tanh), _stream()),
+            "linear_bwd",
+        )
+        return dx, dw, db, None
+
+
+def linear_chw_tanh(x, weight, bias, apply_tanh=True):
+    """x.view(N, -1) in the reference's (C,H,W) order -> Linear -> tanh (warp.py:94-99)."""
+    return _LinearTanhFn.apply(x, weight, bias, apply_tanh)
+
+
+class _TpsGridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, consts, h, w, npts):
+        L = lib()
+        Li, px, py, gx, gy = consts
+        theta = theta.contiguous()
+        b = theta.shape[0]
+        grid = torch.empty((b, h, w, 2), dtype=torch.float32, device=theta.device)
+        ws = workspace(theta.device, L.so_tps_ws_floats(b, h, w, npts) * 4)
+        check(L.so_tps_grid_fwd(theta.data_ptr(), Li.data_ptr(), px.data_ptr(), py.data_ptr(), gx.data_ptr(), gy.data_ptr(),
+                                grid.data_ptr(), b, h, w, npts, ws.data_ptr(), _stream()), "tps_fwd")
+        ctx.consts = consts
+        ctx.cfg = (b, h, w, npts)
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        L = lib()
+        Li, px, py, gx, gy = ctx.consts
+        b, h, w, npts = ctx.cfg
+        dgrid = dgrid.contiguous()
+        dtheta = torch.empty((b, 2 * npts), dtype=torch.float32, device=dgrid.device)
+        ws = workspace(dgrid.device, L.so_tps_ws_floats(b, h, w, npts) * 4)
+        check(L.so_tps_grid_bwd(dgrid.data_ptr(), Li.data_ptr(), px.data_ptr(), py.data_ptr(), gx.data_ptr(), gy.data_ptr(),
+                                dtheta.data_ptr(), b, h, w, npts, ws.data_ptr(), _stream()), "tps_bwd")
+        return dtheta, None, None, None, None
+
+
+def tps_grid(theta, consts, h, w, npts):
+    return _TpsGridFn.apply(theta, consts, h, w, npts)
+
+
+class _GridSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, grid, border):
+        _require_cuda(inp)
+        inp = to_nchw(inp)
+        grid = grid.contiguous()
+        b, c, h, w = inp.shape
+        ho, wo = grid.shape[1], grid.shape[2]
+        out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=inp.device)
+        check(lib().so_grid_sample_fwd(inp.data_ptr(), grid.data_ptr(), out.data_ptr(), None, b, c, h, w, ho, wo, int(border), _stream()), "grid_sample_fwd")
+        ctx.save_for_backward(inp, grid)
+        ctx.border = border
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, grid = ctx.saved_tensors
+        b, c, h, w = inp.shape
+        ho, wo = grid.shape[1], grid.shape[2]
+        dout = to_nchw(dout)
+        dgrid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        din = None
+        if ctx.needs_input_grad[0]:
+            din = torch.empty_like(inp)
+            check(lib().so_fill(din.data_ptr(), din.numel(), 0.0, _stream()), "fill")
+        check(
+            lib().so_grid_sample_bwd(inp.data_ptr(), grid.data_ptr(), dout.data_ptr(),
+                                     dgrid.data_ptr() if dgrid is not None else None,
+                                     din.data_ptr() if din is not None else None,
+                                     b, c, h, w, ho, wo, int(ctx.border), _stream()),
+            "grid_sample_bwd",
+        )
+        return din, dgrid, None
+
+
+def grid_sample(inp, grid, padding_mode="zeros"):
+    """F.grid_sample(inp, grid, mode='bilinear', padding_mode=..., align_corners=False)."""
+    if padding_mode not in ("zeros", "border"):
+        raise NotImplementedError(padding_mode)
+    if inp.is_cuda and not inp.is_contiguous():
+        inp = to_nchw(inp)
+    return _GridSampleFn.apply(inp, grid, padding_mode == "border")
+
+
+def grid_sample_taps(inp, grid, padding_mode="zeros"):
+    """Forward only; also returns the int32 north-west tap indices (x0, y0) per output pixel."""
+    inp = to_nchw(inp)
+    grid = grid.contiguous()
+    b, c, h, w = inp.shape
+    ho, wo = grid.shape[1], grid.shape[2]
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=inp.device)
+    taps = torch.empty((b, ho, wo, 2), dtype=torch.int32, device=inp.device)
+    check(lib().so_grid_sample_fwd(inp.data_ptr(), grid.data_ptr(), out.data_ptr(), taps.data_ptr(), b, c, h, w, ho, wo,
+                                   int(padding_mode == "border"), _stream()), "grid_sample_fwd")
+    return out, taps
+
+
+class _Resample2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, flow):
+        inp, flow = to_nchw(inp), to_nchw(flow)
+        b, c, h, w = inp.shape
+        out = torch.empty_like(inp)
+        check(lib().so_resample2d_fwd(inp.data_ptr(), flow.data_ptr(), out.data_ptr(), b, c, h, w, _stream()), "resample2d_fwd")
+        ctx.save_for_backward(inp, flow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, flow = ctx.saved_tensors
+        b, c, h, w = inp.shape
+        dout = to_nchw(dout)
+        din = dflow = None
+        if ctx.needs_input_grad[0]:
+            din = torch.empty_like(inp)
+            check(lib().so_fill(din.data_ptr(), din.numel(), 0.0, _stream()), "fill")
+        if ctx.needs_input_grad[1]:
+            dflow = torch.empty_like(flow)
+        check(
+            lib().so_resample2d_bwd(inp.data_ptr(), flow.data_ptr(), dout.data_ptr(),
+                                    din.data_ptr() if din is not None else None,
+                                    dflow.data_ptr() if dflow is not None else None, b, c, h, w, _stream()),
+            "resample2d_bwd",
+        )
+        return din, dflow
+
+
+def resample2d(inp, flow):
+    return _Resample2dFn.apply(inp, flow)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses / composition
+# ------------------------------------------------------------------------------------------------
+class _L1LossFn(torch.autograd.Function):
+    """mean |a - b| * weight  (gradient flows to `a` only, as at every reference call site)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight):
+        L = lib()
+        _require_cuda(a)
+        if a.shape != b.shape:
+            raise ValueError("l1_loss: shape mismatch")
+        rows_mode = a.dim() == 4 and not (a.is_contiguous() and b.is_contiguous())
+        if rows_mode:
+            a2, b2 = to_rows(a), to_rows(b)
+            n, c, h, w = a2.shape
+            lda, ldb, rows = _ld(a2), _ld(b2), n * h * w
+        else:
+            a2, b2 = a.contiguous(), b.contiguous()
+            rows, c = 1, a2.numel()
+            lda = ldb = c
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = workspace(a.device)
+        scale = weight / a.numel()
+        check(L.so_l1_loss_fwd(a2.data_ptr(), lda, b2.data_ptr(), ldb, rows, c, scale, out.data_ptr(), 0, ws.data_ptr(), _stream()), "l1_fwd")
+        ctx.save_for_backward(a2, b2)
+        ctx.cfg = (lda, ldb, rows, c, scale, tuple(a.shape), rows_mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a2, b2 = ctx.saved_tensors
+        lda, ldb, rows, c, scale, shape, rows_mode = ctx.cfg
+        gout = gout.contiguous()
+        if rows_mode:
+            n, ch, h, w = shape
+            da = nhwc_empty(n, h, w, ch, a2.device)
+        else:
+            da = torch.empty(shape, dtype=torch.float32, device=a2.device)
+        check(lib().so_l1_loss_bwd(a2.data_ptr(), lda, b2.data_ptr(), ldb, gout.data_ptr(), scale, da.data_ptr(), c, rows, c, 0, _stream()), "l1_bwd")
+        return da, None, None
+
+
+def l1_loss(a, b, weight=1.0):
+    return _L1LossFn.apply(a, b, float(weight))
+
+
+class _TryonComposeFn(torch.autograd.Function):
+    """tanh / sigmoid / blend of UnetMaskModel.forward for one frame (unet_mask_model.py:84-86,126-129)."""
+
+    @staticmethod
+    def forward(ctx, o, cloth):
+        L = lib()
+        o, cloth = to_rows(o), to_rows(cloth)
+        n, c, h, w = o.shape
+        dev = o.device
+        rendered = nhwc_empty(n, h, w, 3, dev, ld=4)
+        mask = nhwc_empty(n, h, w, 1, dev)
+        tryon = nhwc_empty(n, h, w, 3, dev, ld=4)
+        check(
+            L.so_tryon_compose_fwd(o.data_ptr(), _ld(o), cloth.data_ptr(), _ld(cloth), rendered.data_ptr(), 4,
+                                   mask.data_ptr(), 1, tryon.data_ptr(), 4, 4, n * h * w, _stream()),
+            "compose_fwd",
+        )
+        ctx.save_for_backward(rendered, mask, cloth)
+        ctx.cfg = (n, c, h, w)
+        return rendered, mask, tryon
+
+    @staticmethod
+    def backward(ctx, d_rendered, d_mask, d_tryon):
+        rendered, mask, cloth = ctx.saved_tensors
+        n, c, h, w = ctx.cfg
+        dev = rendered.device
+        d_o = nhwc_empty(n, h, w, c, dev)
+        if c > 4:
+            check(lib().so_fill(d_o.data_ptr(), d_o.numel(), 0.0, _stream()), "fill")
+
+        def prep(t):
+            if t is None:
+                return None, 0
+            t = to_rows(t)
+            return t, _ld(t)
+
+        dr, lddr = prep(d_rendered)
+        dm, lddm = prep(d_mask)
+        dt, lddt = prep(d_tryon)
+        check(
+            lib().so_tryon_compose_bwd(
+                rendered.data_ptr(), 4, mask.data_ptr(), 1, cloth.data_ptr(), _ld(cloth),
+                dt.data_ptr() if dt is not None else None, lddt,
+                dr.data_ptr() if dr is not None else None, lddr,
+                dm.data_ptr() if dm is not None else None, lddm,
+                d_o.data_ptr(), c, n * h * w, _stream(),
+            ),
+            "compose_bwd",
+        )
+        return d_o, None
+
+
+def tryon_compose(o, cloth):
+    return _TryonComposeFn.apply(o, cloth)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """Fused Adam on flat fp32 slabs (torch.optim.Adam semantics, base_model.py:165-168)."""
+    check(lib().so_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                             int(step), grad_scale, _stream()), "adam_step")
+
+
+def fill_(t, value=0.0):
+    check(lib().so_fill(t.data_ptr(), t.numel(), float(value), _stream()), "fill")
+    return t
+
+
+class _BlendFn(torch.autograd.Function):
+    """(1 - m) * a + m * b with a one-channel mask m (multi-frame path, unet_mask_model.py:118-129)."""
+
+    @staticmethod
+    def forward(ctx, a, b, m):
+        a, b, m = to_rows(a), to_rows(b), to_rows(m)
+        n, c, h, w = a.shape
+        out = nhwc_empty(n, h, w, c, a.device)
+        check(lib().so_blend_fwd(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), m.data_ptr(), _ld(m), out.data_ptr(), c,
+                                 n * h * w, c, _stream()), "blend_fwd")
+        ctx.save_for_backward(a, b, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, m = ctx.saved_tensors
+        n, c, h, w = a.shape
+        g = to_rows(g)
+        dev = a.device
+        da = nhwc_empty(n, h, w, c, dev) if ctx.needs_input_grad[0] else None
+        db = nhwc_empty(n, h, w, c, dev) if ctx.needs_input_grad[1] else None
+        dm = nhwc_empty(n, h, w, 1, dev) if ctx.needs_input_grad[2] else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        check(lib().so_blend_bwd(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), m.data_ptr(), _ld(m), g.data_ptr(), _ld(g),
+                                 p(da), c, p(db), c, p(dm), 1, n * h * w, c, _stream()), "blend_bwd")
+        return da, db, dm
+
+
+def blend(a, b, m):
+    return _BlendFn.apply(a, b, m)
+
+
+class _SumFn(torch.autograd.Function):
+    """tensor.sum() (flow-mask penalty, unet_mask_model.py:186-188) as <x, 1>."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = to_rows(x) if x.dim() == 4 else x.contiguous()
+        ones = torch.empty(x2.numel(), dtype=torch.float32, device=x.device)
+        fill_(ones, 1.0)
+        xc = _copy_rows(x2) if x.dim() == 4 and _ld(x2) != x2.shape[1] else x2
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device)
+        check(lib().so_dot(xc.data_ptr(), xc.numel(), ones.data_ptr(), xc.numel(), 1, xc.numel(), 1.0, out.data_ptr(),
+                           ws.data_ptr(), _stream()), "dot")
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        if len(shape) == 4:
+            out = nhwc_empty(shape[0], shape[2], shape[3], shape[1], g.device)
+        else:
+            out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        n = out.numel()
+        ones = fill_(torch.empty(n, dtype=torch.float32, device=g.device), 1.0)
+        zeros = fill_(torch.empty(n, dtype=torch.float32, device=g.device), 0.0)
+        g = g.contiguous()
+        # out = g * 1 + 0 (g is a device scalar)
+        check(lib().so_scale_add(ones.data_ptr(), n, g.data_ptr(), zeros.data_ptr(), n, out.data_ptr(), n, 1, n,
+                                 _stream()), "scale_add")
+        return out
+
+
+def tensor_sum(x):
+    return _SumFn.apply(x)

@@ -1,0 +1,169 @@
+"""UnetMaskModel — the CP-VTON try-on module (reference: models/unet_mask_model.py:27-326).
+
+forward: cat(person, cloth) -> U-Net -> tanh (rendered person) | sigmoid (try-on mask) [| sigmoid (flow
+mask)] -> p_tryon = (1 - mask) * p_rendered + mask * warped_cloth, per frame.
+training_step: L1(p_tryon, image) + VGG(p_tryon, image) + L1(mask, cloth_mask) + pen * sum(flow_mask).
+"""
+import argparse
+import logging
+import math
+import os.path as osp
+
+import torch
+
+from . import ops
+from .base_model import BaseModel
+from .io_png import get_save_paths, save_images
+from .networks import init_weights
+from .networks.cpvton.unet import UnetGenerator
+from .networks.layers import HipInstanceNorm2d
+from .networks.loss import VGGLoss
+from .pl_compat import EvalResult, TrainResult
+from .tryon_channels import RGB_CHANNELS
+from .util import get_and_cat_inputs, maybe_combine_frames_and_channels
+
+logger = logging.getLogger("logger")
+
+
+class Resample2d(torch.nn.Module):
+    """Flow warp of the previous generated frame (flownet2 Resample2d, kernel_size=1, bilinear)."""
+
+    def forward(self, input1, input2):
+        return ops.resample2d(input1, input2)
+
+
+class UnetMaskModel(BaseModel):
+    """ CP-VTON Try-On Module (TOM) """
+
+    @classmethod
+    def modify_commandline_options(cls, parser: argparse.ArgumentParser, is_train):
+        parser = argparse.ArgumentParser(parents=[parser], add_help=False)
+        parser = super(UnetMaskModel, cls).modify_commandline_options(parser, is_train)
+        parser.set_defaults(person_inputs=("agnostic", "densepose"))
+        parser.add_argument("--pen_flow_mask", type=float, default=1.0, help="Penalty applied to flow mask loss")
+        return parser
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        if isinstance(hparams, dict):
+            hparams = argparse.Namespace(**hparams)
+        self.hparams = hparams
+        n_frames = hparams.n_frames_total if hasattr(hparams, "n_frames_total") else 1
+        self.unet = UnetGenerator(
+            input_nc=(self.person_channels + self.cloth_channels) * n_frames,
+            output_nc=5 * n_frames if self.hparams.flow_warp else 4 * n_frames,
+            num_downs=6,
+            num_attention=hparams.num_attn if hasattr(hparams, "num_attn") else 2,
+            ngf=int(64 * (math.log(n_frames) + 1)),
+            norm_layer=HipInstanceNorm2d,
+            use_self_attn=hparams.self_attn,
+            activation=hparams.activation,
+        )
+        self.resample = Resample2d()
+        self.criterionVGG = VGGLoss()
+        init_weights(self.unet, init_type="normal")
+
+    def forward(self, person_representation, warped_cloths, flows=None, prev_im=None):
+        n = self.hparams.n_frames_total
+        concat_tensor = ops.cat_channels([person_representation, warped_cloths])
+        outputs = self.unet(concat_tensor)
+
+        if n == 1 and not self.hparams.flow_warp:
+            # single frame: tanh | sigmoid | blend fused in one kernel
+            p_rendereds, tryon_masks, p_tryons = ops.tryon_compose(outputs, warped_cloths)
+            return p_rendereds, tryon_masks, p_tryons, None
+
+        boundary, weight_boundary = 3 * n, 4 * n
+        p_rendereds = ops.activation(outputs[:, 0:boundary], "tanh")
+        tryon_masks = ops.activation(outputs[:, boundary:weight_boundary], "sigmoid")
+        flow_masks = ops.activation(outputs[:, weight_boundary:], "sigmoid") if self.hparams.flow_warp else None
+
+        flows = list(torch.chunk(flows, n, dim=1)) if flows is not None else None
+        cloths = list(torch.chunk(warped_cloths, n, dim=1))
+        rend = list(torch.chunk(p_rendereds, n, dim=1))
+        masks = list(torch.chunk(tryon_masks, n, dim=1))
+        fmasks = list(torch.chunk(flow_masks, n, dim=1)) if flow_masks is not None else None
+
+        frames = []
+        for f in range(n):
+            if flows is not None and f > 0:
+                warped_by_flow = self.resample(frames[f - 1], flows[f])
+                p_rendered = ops.blend(warped_by_flow, rend[f], fmasks[f])
+            else:
+                p_rendered = rend[f]
+            frames.append(ops.blend(p_rendered, cloths[f], masks[f]))
+        p_tryons = ops.cat_channels(frames)
+        return p_rendereds, tryon_masks, p_tryons, flow_masks
+
+    def training_step(self, batch, batch_idx, val=False):
+        hp = self.hparams
+        n = hp.n_frames_total
+        batch = maybe_combine_frames_and_channels(hp, batch)
+        im, prev_im, cm = batch["image"], batch.get("prev_image"), batch["cloth_mask"]
+        flow = batch["flow"] if hp.flow_warp else None
+        person_inputs = get_and_cat_inputs(batch, hp.person_inputs)
+        cloth_inputs = get_and_cat_inputs(batch, hp.cloth_inputs)
+
+        p_rendereds, tryon_masks, p_tryons, flow_masks = self.forward(person_inputs, cloth_inputs, flow, prev_im)
+        self.p_tryons = torch.chunk(p_tryons, n, dim=1)
+        self.p_rendereds = torch.chunk(p_rendereds, n, dim=1)
+        self.tryon_masks = torch.chunk(tryon_masks, n, dim=1)
+        self.flow_masks = torch.chunk(flow_masks, n, dim=1) if flow_masks is not None else None
+        im = torch.chunk(im, n, dim=1)
+        cm = torch.chunk(cm, n, dim=1)
+
+        def both(fn):
+            """term on the last frame; averaged with the one before it when n > 1 (unet_mask_model.py:174-184)"""
+            curr = fn(-1)
+            if n > 1:
+                prev = fn(-2)
+                return 0.5 * (curr + prev), curr, prev
+            return curr, curr, torch.zeros_like(curr)
+
+        loss_image_l1, l1_curr, l1_prev = both(lambda i: ops.l1_loss(self.p_tryons[i], im[i]))
+        loss_image_vgg, vgg_curr, vgg_prev = both(lambda i: self.criterionVGG(self.p_tryons[i], im[i]))
+        loss_tryon_mask_l1, m_curr, m_prev = both(lambda i: ops.l1_loss(self.tryon_masks[i], cm[i]))
+        if self.flow_masks is not None:
+            loss_flow_mask_l1 = ops.tensor_sum(self.flow_masks[-1]) * hp.pen_flow_mask
+        else:
+            loss_flow_mask_l1 = torch.zeros_like(m_curr) * hp.pen_flow_mask
+
+        loss = loss_image_l1 + loss_image_vgg + loss_tryon_mask_l1 + loss_flow_mask_l1
+
+        if not val and self.global_step % hp.display_count == 0:
+            self.visualize(batch)
+        val_ = "val_" if val else ""
+        result = EvalResult(checkpoint_on=loss) if val else TrainResult(loss)
+        result.log(f"{val_}loss/G", loss, prog_bar=True)
+        result.log(f"{val_}loss/G/l1", loss_image_l1, prog_bar=True)
+        result.log(f"{val_}loss/G/vgg", loss_image_vgg, prog_bar=True)
+        result.log(f"{val_}loss/G/tryon_mask_l1", loss_tryon_mask_l1, prog_bar=True)
+        result.log(f"{val_}loss/G/flow_mask_l1", loss_flow_mask_l1, prog_bar=True)
+        if n > 1:
+            result.log(f"{val_}loss/G/l1_prev", l1_prev)
+            result.log(f"{val_}loss/G/vgg_prev", vgg_prev)
+            result.log(f"{val_}loss/G/tryon_mask_prev", m_prev)
+            result.log(f"{val_}loss/G/l1_curr", l1_curr)
+            result.log(f"{val_}loss/G/vgg_curr", vgg_curr)
+            result.log(f"{val_}loss/G/tryon_mask_curr", m_curr)
+        return result
+
+    def test_step(self, batch, batch_idx):
+        hp = self.hparams
+        batch = maybe_combine_frames_and_channels(hp, batch)
+        dataset_names, im_names = batch["dataset_name"], batch["image_name"]
+        if hp.n_frames_total > 1:
+            dataset_names = [seq[-1] for seq in dataset_names]
+            im_names = [seq[-1] for seq in im_names]
+        task = "tryon" if getattr(hp, "tryon_list", None) else "reconstruction"
+        try_on_dirs = [osp.join(self.test_results_dir, d, task) for d in dataset_names]
+        save_paths = get_save_paths(try_on_dirs, im_names)
+        if all(osp.exists(s) for s in save_paths):
+            progress_bar = {"file": f"Skipping {im_names[0]}"}
+        else:
+            progress_bar = {"file": f"{im_names[0]}"}
+            person_inputs = get_and_cat_inputs(batch, hp.person_inputs)
+            cloth_inputs = get_and_cat_inputs(batch, hp.cloth_inputs)
+            _, _, self.p_tryon, _ = self.forward(person_inputs, cloth_inputs)
+            save_images(self.p_tryon[:, -RGB_CHANNELS:], im_names, try_on_dirs)
+        return {"progress_bar": progress_bar}

@@ -1,0 +1,93 @@
+"""WarpModel — the geometric matching module (reference: models/warp_model.py:27-152).
+
+forward: features(person), features(cloth) -> L2 norm -> correlation -> regression -> theta -> TPS grid.
+training_step: L1(grid_sample(cloth, grid, border), im_cloth).
+"""
+import argparse
+import os.path as osp
+from argparse import ArgumentParser
+
+from torch import nn
+
+from . import ops
+from .base_model import BaseModel
+from .io_png import get_save_paths, save_images
+from .networks.cpvton.warp import (FeatureCorrelation, FeatureExtraction, FeatureL2Norm, FeatureRegression,
+                                   TpsGridGen)
+from .pl_compat import EvalResult, TrainResult
+from .util import get_and_cat_inputs, maybe_combine_frames_and_channels
+
+
+class WarpModel(BaseModel):
+    """ Geometric Matching Module """
+
+    @classmethod
+    def modify_commandline_options(cls, parser: ArgumentParser, is_train):
+        parser = ArgumentParser(parents=[parser], add_help=False)
+        parser = super(WarpModel, cls).modify_commandline_options(parser, is_train)
+        parser.add_argument("--grid_size", type=int, default=5)
+        parser.set_defaults(person_inputs=("agnostic", "cocopose"))
+        return parser
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        if isinstance(hparams, dict):
+            hparams = argparse.Namespace(**hparams)
+        self.extractionA = FeatureExtraction(self.person_channels, ngf=hparams.ngf, n_layers=3)
+        self.extractionB = FeatureExtraction(self.cloth_channels, ngf=hparams.ngf, n_layers=3)
+        self.l2norm = FeatureL2Norm()
+        self.correlation = FeatureCorrelation()
+        self.regression = FeatureRegression(input_nc=192, output_dim=2 * hparams.grid_size ** 2)
+        self.gridGen = TpsGridGen(hparams.fine_height, hparams.fine_width, grid_size=hparams.grid_size)
+
+    def forward(self, inputA, inputB):
+        featureA = self.extractionA(inputA)
+        featureB = self.extractionB(inputB)
+        featureA = self.l2norm(featureA, transpose_hw=True)  # the h<->w transpose of warp.py:60 is fused here
+        featureB = self.l2norm(featureB)
+        correlation = self.correlation(featureA, featureB, a_is_transposed=True)
+        theta = self.regression(correlation)
+        grid = self.gridGen(theta)
+        return grid, theta
+
+    def training_step(self, batch, idx, val=False):
+        batch = maybe_combine_frames_and_channels(self.hparams, batch)
+        c, im_c = batch["cloth"], batch["im_cloth"]
+        person_inputs = get_and_cat_inputs(batch, self.hparams.person_inputs)
+        cloth_inputs = get_and_cat_inputs(batch, self.hparams.cloth_inputs)
+
+        grid, theta = self.forward(person_inputs, cloth_inputs)
+        self.warped_cloth = ops.grid_sample(c, grid, padding_mode="border")
+        if "grid_vis" in batch:  # visual only, no loss (warp_model.py:86)
+            self.warped_grid = ops.grid_sample(batch["grid_vis"], grid.detach(), padding_mode="zeros")
+        loss = ops.l1_loss(self.warped_cloth, im_c)
+
+        if not val and self.global_step % self.hparams.display_count == 0:
+            self.visualize(batch)
+        val_ = "val_" if val else ""
+        result = EvalResult(checkpoint_on=loss) if val else TrainResult(loss)
+        result.log(f"{val_}loss/G", loss, prog_bar=True)
+        return result
+
+    def test_step(self, batch, batch_idx):
+        batch = maybe_combine_frames_and_channels(self.hparams, batch)
+        dataset_names = batch["dataset_name"]
+        warp_cloth_dirs = [osp.join(self.test_results_dir, d, "warp-cloth") for d in dataset_names]
+        warp_mask_dirs = [osp.join(self.test_results_dir, d, "warp-mask") for d in dataset_names]
+        c_names = batch["cloth_name"]
+        save_paths = get_save_paths(warp_cloth_dirs, c_names)
+        if all(osp.exists(s) for s in save_paths):
+            progress_bar = {"file": f"Skipping {c_names[0]}"}
+        else:
+            progress_bar = {"file": c_names[0]}
+            c, cm = batch["cloth"], batch["cloth_mask"]
+            person_inputs = get_and_cat_inputs(batch, self.hparams.person_inputs)
+            cloth_inputs = get_and_cat_inputs(batch, self.hparams.cloth_inputs)
+            grid, theta = self.forward(person_inputs, cloth_inputs)
+            self.warped_cloth = ops.grid_sample(c, grid, padding_mode="border")
+            warped_mask = ops.grid_sample(cm, grid, padding_mode="zeros")
+            if "grid_vis" in batch:
+                self.warped_grid = ops.grid_sample(batch["grid_vis"], grid, padding_mode="zeros")
+            save_images(self.warped_cloth, c_names, warp_cloth_dirs)
+            save_images(warped_mask * 2 - 1, c_names, warp_mask_dirs)
+        return {"progress_bar": progress_bar}
