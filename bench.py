@@ -1,0 +1,199 @@
+"""Headline benchmark: try-on frames/sec (forward+backward+Adam) at 256x192, bs=4 per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is the chained warp -> try-on training step of SURVEY.md §8d (C4 at the BASELINE batch size):
+WarpModel (GMM) training step, then UnetMaskModel (self-attention, num_attn=2, GELU, L1 + VGG + mask
+loss) training step on the detached warped cloth, each with its Adam update; under N > 1 each rank works
+on its own 4 frames (weak scaling) and gradients are mean-all-reduced over RCCL.
+Inputs are synthetic (seed 420) and resident in HBM before the timed region; weights are random-init.
+
+Rank 0 prints ONE JSON line.  `roofline` is the live HIP-event measurement of the dominant MFMA kernel
+(algorithmic FLOPs / summed kernel time inside the timed region); `cpu_baseline` is the oracle (a CPU
+restatement of the reference, kind "port") timed on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import shineon_virtual_tryon_amd as pkg  # noqa: E402
+from shineon_virtual_tryon_amd.data import synthetic_batch  # noqa: E402
+from shineon_virtual_tryon_amd.trainer import GradientAllReducer, broadcast_parameters, init_distributed  # noqa: E402
+from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel  # noqa: E402
+from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+KEY_NAMES = ["fprop64", "fprop128", "dgrad64", "dgrad128", "wgrad64", "wgrad128", "gemm64", "gemm128"]
+
+
+def hparams(**kw):
+    base = dict(n_frames_total=1, cloth_inputs=["cloth"], is_train=True, ngf=64, grid_size=5, fine_height=256,
+                fine_width=192, self_attn=True, num_attn=2, flow_warp=False, activation="gelu", display_count=10 ** 9,
+                pen_flow_mask=1.0, lr=1e-4, keep_epochs=5, decay_epochs=5)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def cpu_baseline(batch_size, iters=2):
+    """The oracle (CPU restatement of the reference path) on this host's cores: same chained step."""
+    from oracle import shineon_oracle as oracle
+    from oracle.procedural import procedural_state_dict, shapes_of
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    warp_sd = procedural_state_dict(shapes_of(WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).state_dict()))
+    unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).state_dict()))
+    wp = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in warp_sd.items()}
+    up = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in unet_sd.items()}
+    optw = torch.optim.Adam([v for v in wp.values() if v.requires_grad], 1e-4)
+    optu = torch.optim.Adam([v for v in up.values() if v.requires_grad], 1e-4)
+    batch = synthetic_batch(batch_size, "cpu")
+    consts = oracle.tps_constants(256, 192, 5)
+    whp = dict(person_inputs=["agnostic", "cocopose"], cloth_inputs=["cloth"])
+    uhp = dict(n_frames_total=1, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], self_attn=True,
+               num_attn=2, activation="gelu", flow_warp=False)
+
+    def step():
+        optw.zero_grad()
+        out = oracle.warp_losses(wp, batch, whp, consts)
+        out["loss/G"].backward()
+        optw.step()
+        b2 = dict(batch)
+        b2["cloth"] = out["warped_cloth"].detach()
+        optu.zero_grad()
+        oracle.unet_mask_losses(up, b2, uhp)["loss/G"].backward()
+        optu.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": batch_size / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 warm-up + {iters} timed chained steps (WarpModel + UnetMaskModel fwd+bwd+Adam, bs={batch_size}, "
+                      f"256x192) with PyTorch CPU fp32, {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU (BASELINE: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    args = ap.parse_args()
+
+    rank, world = init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    L = pkg.lib()
+
+    torch.manual_seed(420)
+    warp = WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).to(dev).train()
+    unet = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).to(dev).train()
+    warp.global_step = unet.global_step = 1
+    broadcast_parameters(warp)
+    broadcast_parameters(unet)
+    (optw,), _ = warp.configure_optimizers()
+    (optu,), _ = unet.configure_optimizers()
+    optw.zero_grad()
+    optu.zero_grad()
+    redw, redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads)
+    batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch)
+
+    def step():
+        optw.zero_grad()
+        res = warp.training_step(batch, 0)
+        res.minimize.backward()
+        optw.step(grad_scale=redw.all_reduce())
+        b2 = dict(batch)
+        b2["cloth"] = warp.warped_cloth.detach()
+        optu.zero_grad()
+        res = unet.training_step(b2, 0)
+        res.minimize.backward()
+        optu.step(grad_scale=redu.all_reduce())
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    L.so_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    L.so_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms = (ctypes.c_float * 8)()
+    fl = (ctypes.c_float * 8)()
+    cnt = (ctypes.c_int * 8)()
+    L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
+
+    if rank == 0:
+        kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / args.steps,
+                                  "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
+                   for k in range(8) if cnt[k] > 0}
+        dom = max(range(8), key=lambda k: ms[k])
+        achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        mfma_ms = sum(ms) / args.steps
+        out = {
+            "metric": "try-on frames/sec (fwd+bwd) at 256x192 bs=4",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32",
+            "data": "synthetic",
+            "config": {
+                "workload": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then "
+                            "UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, "
+                            "256x192",
+                "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+            },
+            "roofline": {
+                "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None, "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+                "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / (1e3 * elapsed / args.steps),
+                "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
+            },
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

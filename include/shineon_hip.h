@@ -64,6 +64,13 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
 /* test hook: force the block tile (128 / 64, 0 = auto) and split-K factor (0 = auto). */
 void so_igemm_force(int bm, int splitk);
 
+/* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
+ * stream.  so_prof_collect waits for them and fills HOST arrays of 8 entries, key = mode*2 + (tile==128)
+ * with mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm: summed milliseconds, summed algorithmic FLOPs
+ * (2*M*N*K per launch), launch count.  Returns the number of launches collected and clears the list. */
+void so_prof_enable(int on);
+int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
+
 /* ---- normalisation (csrc/norm.hip) ---------------------------------------------------------------- */
 
 /* floats of scratch needed by so_norm_fwd / so_norm_bwd */

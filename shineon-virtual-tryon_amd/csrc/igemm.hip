@@ -468,6 +468,29 @@ static SoPlan so_plan(const SoIgemm& p, long long ws_floats, int force_bm, int f
 
 static int g_force_bm = 0, g_force_splitk = 0;
 
+// ---- optional live timing of every MFMA launch with HIP events (bench.py's roofline figure) --------
+// Events are recorded on the launch stream around the main kernel only (not the split-K reduce).
+#include <vector>
+struct SoProfRec {
+  hipEvent_t e0, e1;
+  int key;  // MODE * 2 + (BM == 128)
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<SoProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t so_prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
 template <int MODE, bool A_MC, bool B_MC, int BM>
 static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   constexpr int A_STAGE = A_MC ? 32 * BM : BM * 36;
@@ -483,7 +506,19 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   }
   const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BM);
   dim3 grid((unsigned)tiles, 1, (unsigned)(p.nclass * p.splitk));
+  SoProfRec rec;
+  if (g_prof_on) {
+    rec.e0 = so_prof_event();
+    rec.e1 = so_prof_event();
+    rec.key = MODE * 2 + (BM == 128 ? 1 : 0);
+    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
+    hipEventRecord(rec.e0, stream);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+  if (g_prof_on) {
+    hipEventRecord(rec.e1, stream);
+    g_prof.push_back(rec);
+  }
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
   if (p.splitk > 1) {
@@ -513,6 +548,29 @@ extern "C" {
 void so_igemm_force(int bm, int splitk) {
   g_force_bm = bm;
   g_force_splitk = splitk;
+}
+
+void so_prof_enable(int on) { g_prof_on = on != 0; }
+
+// Waits for every recorded launch, then fills per-key totals (key = mode*2 + (tile==128), 8 keys):
+// out_ms[k] = summed kernel time in ms, out_flops[k] = summed algorithmic FLOPs, out_count[k] = launches.
+// Clears the record list.  Returns the number of launches collected.
+int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
+  for (int k = 0; k < 8; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
+  int n = 0;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      out_ms[r.key] += ms;
+      out_flops[r.key] += (float)r.flops;
+      out_count[r.key] += 1;
+      ++n;
+    }
+    g_prof_pool.push_back(r.e0);
+    g_prof_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return n;
 }
 
 int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,

@@ -20,9 +20,26 @@ _KEYS = {
 _MASKS = ("cloth_mask", "silhouette")
 
 
-def synthetic_sample(index, height=256, width=192, n_frames=1, seed=420, radius=5):
-    """One sample of the batch dict: images U(-1,1), masks Bernoulli(.5), cocopose -1 with 11x11 +1 squares,
-    flow N(0, 2) px; tensors are (C, H, W) or (n_frames, C, H, W)."""
+def _smooth_field(rng, shape):
+    """Band-limited image in [-1, 1]: two random low-frequency sinusoids per channel.  Used by the parity
+    fixtures: with white-noise images d(grid_sample)/d(grid) flips with every tap change, which turns a 1e-5
+    difference in the grid into O(1) differences in the gradients (an input property, not a kernel one)."""
+    n, c, h, w = shape
+    y = np.arange(h, dtype=np.float64)[:, None] / h
+    x = np.arange(w, dtype=np.float64)[None, :] / w
+    out = np.empty(shape, np.float32)
+    for f in range(n):
+        for k in range(c):
+            fx, fy = rng.integers(1, 4, 2), rng.integers(1, 4, 2)
+            ph = rng.uniform(0, 2 * np.pi, 2)
+            out[f, k] = (0.55 * np.sin(2 * np.pi * (fx[0] * x + fy[0] * y) + ph[0])
+                         + 0.4 * np.sin(2 * np.pi * (fx[1] * x - fy[1] * y) + ph[1]))
+    return out
+
+
+def synthetic_sample(index, height=256, width=192, n_frames=1, seed=420, radius=5, smooth=False):
+    """One sample of the batch dict: images U(-1,1) (or band-limited when smooth=True), masks Bernoulli(.5),
+    cocopose -1 with 11x11 +1 squares, flow N(0, 2) px; tensors are (C, H, W) or (n_frames, C, H, W)."""
     rng = np.random.default_rng([seed, index])
     out = {}
     for key, c in _KEYS.items():
@@ -37,6 +54,8 @@ def synthetic_sample(index, height=256, width=192, n_frames=1, seed=420, radius=
                     a[f, k, max(0, y - radius):y + radius + 1, max(0, x - radius):x + radius + 1] = 1.0
         elif key == "flow":
             a = rng.normal(0.0, 2.0, shape).astype(np.float32)
+        elif smooth:
+            a = _smooth_field(rng, shape)
         else:
             a = rng.uniform(-1.0, 1.0, shape).astype(np.float32)
         t = torch.from_numpy(a)
@@ -44,7 +63,9 @@ def synthetic_sample(index, height=256, width=192, n_frames=1, seed=420, radius=
     name = f"synthetic_{index:06d}.png"
     for key in ("dataset_name", "cloth_name", "cloth_path", "image_name", "image_path"):
         val = "SyntheticDataset" if key == "dataset_name" else name
-        out[key] = [val] * n_frames if n_frames > 1 else val
+        # like the reference's NFramesInterface (n_frames_interface.py:79-100): strings arrive as one list per
+        # frame, which maybe_combine_frames_and_channels unwraps when n_frames_total == 1
+        out[key] = [val] * n_frames
     return out
 
 
@@ -75,11 +96,12 @@ class SyntheticDataset(Dataset):
         return parser
 
 
-def synthetic_batch(batch_size, device, height=256, width=192, n_frames=1, seed=420, start=0):
+def synthetic_batch(batch_size, device, height=256, width=192, n_frames=1, seed=420, start=0, smooth=False):
     """Collated batch of synthetic samples already resident on `device`."""
     from torch.utils.data.dataloader import default_collate
 
-    batch = default_collate([synthetic_sample(start + i, height, width, n_frames, seed) for i in range(batch_size)])
+    batch = default_collate([synthetic_sample(start + i, height, width, n_frames, seed, smooth=smooth)
+                             for i in range(batch_size)])
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 

@@ -1,0 +1,238 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own modules (imported from /root/reference
+through an in-memory shim for its missing third-party imports) on procedural weights and synthetic inputs.
+
+Runs only in the build container (needs /root/reference); the committed .npz files are what travels.
+Nothing of the reference's source is copied: the shim only provides stand-ins for torchvision /
+pytorch_lightning / tensorboard / the empty flownet2 submodule so that `import models.warp_model` works.
+
+    python tests/golden/make_golden.py
+"""
+import argparse
+import collections
+import collections.abc
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import shineon_oracle as oracle  # noqa: E402  (only for the Resample2d stand-in)
+from oracle.procedural import procedural_state_dict, shapes_of  # noqa: E402
+
+import shineon_virtual_tryon_amd  # noqa: E402,F401
+from shineon_virtual_tryon_amd.data import synthetic_batch  # noqa: E402  (pure numpy generator)
+
+
+# ------------------------------------------------------------------------------------------------
+# shim
+# ------------------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_shim():
+    collections.Iterable = collections.abc.Iterable
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    tv = _mod("torchvision")
+    tv.transforms = _mod("torchvision.transforms", CenterCrop=_Dummy, Normalize=_Dummy, Compose=_Dummy,
+                         ToTensor=_Dummy, Resize=_Dummy)
+    tv.utils = _mod("torchvision.utils", save_image=lambda *a, **k: None, make_grid=lambda *a, **k: None)
+
+    def vgg19(pretrained=False):
+        cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M",
+               512, 512, 512, 512, "M"]
+        layers, cin = [], 3
+        for v in cfg:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        return types.SimpleNamespace(features=nn.Sequential(*layers))
+
+    tv.models = _mod("torchvision.models", vgg19=vgg19)
+
+    class Resample2d(nn.Module):
+        def forward(self, a, b):
+            return oracle.resample2d(a, b)
+
+    _mod("models.flownet2_pytorch")
+    _mod("models.flownet2_pytorch.utils")
+    _mod("models.flownet2_pytorch.utils.flow_utils", flow2img=lambda *a: None, readFlow=lambda *a: None)
+    _mod("models.flownet2_pytorch.networks")
+    _mod("models.flownet2_pytorch.networks.resample2d_package")
+    _mod("models.flownet2_pytorch.networks.resample2d_package.resample2d", Resample2d=Resample2d)
+
+    class _Result:
+        def __init__(self, minimize=None, checkpoint_on=None, **k):
+            self.minimize, self.checkpoint_on, self.logs = minimize, checkpoint_on, {}
+
+        def log(self, name, value, **k):
+            self.logs[name] = value
+
+    class LightningModule(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.global_step = 1  # never 0: skips visualize()
+
+    pl = _mod("pytorch_lightning", LightningModule=LightningModule, TrainResult=_Result, EvalResult=_Result,
+              Trainer=object, Callback=object)
+    pl.callbacks = _mod("pytorch_lightning.callbacks", ModelCheckpoint=object, Callback=object)
+    _mod("torch.utils.tensorboard", SummaryWriter=object)
+    nn.Module.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def hp_namespace(**kw):
+    base = dict(n_frames_total=1, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], is_train=True, ngf=64,
+                grid_size=5, fine_height=256, fine_width=192, self_attn=False, num_attn=2, flow_warp=False,
+                activation=None, display_count=10 ** 9, pen_flow_mask=1.0)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def strided(t, s=8):
+    return t.detach()[..., ::s, ::s].contiguous().numpy()
+
+
+def checksums(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def grad_checksums(module):
+    return {k: checksums(p.grad) for k, p in module.named_parameters() if p.grad is not None}
+
+
+# ------------------------------------------------------------------------------------------------
+# generators
+# ------------------------------------------------------------------------------------------------
+def gen_warp(out):
+    from models.warp_model import WarpModel
+
+    hp = hp_namespace(person_inputs=["agnostic", "cocopose"])
+    torch.manual_seed(0)
+    model = WarpModel(hp)
+    model.load_state_dict(procedural_state_dict(shapes_of(model.state_dict())))
+    model.train()
+    batch = synthetic_batch(2, "cpu", smooth=True)
+    res = model.training_step(batch, 0)
+    res.minimize.backward()
+    person = torch.cat([batch[k] for k in hp.person_inputs], 1)
+    model2 = WarpModel(hp)
+    model2.load_state_dict(procedural_state_dict(shapes_of(model2.state_dict())))
+    model2.train()
+    with torch.no_grad():
+        grid, theta = model2(person, batch["cloth"])
+    g = model.gridGen
+    data = {
+        "loss": np.float64(res.minimize.item()), "theta": theta.numpy(), "grid_s8": strided(grid.permute(0, 3, 1, 2)),
+        "grid_cs": checksums(grid), "warped_cloth_s8": strided(model.warped_cloth), "warped_cloth_cs": checksums(model.warped_cloth),
+        "grad_linear_weight": model.regression.linear.weight.grad.numpy(),
+        "grad_linear_bias": model.regression.linear.bias.grad.numpy(),
+        "bn_rm_A2": model.extractionA.model[2].running_mean.numpy(), "bn_rv_A2": model.extractionA.model[2].running_var.numpy(),
+        "bn_rm_R10": model.regression.conv[10].running_mean.numpy(), "bn_rv_R10": model.regression.conv[10].running_var.numpy(),
+        "Li": g.Li[0].numpy(), "P_X_base": g.P_X_base.numpy(), "P_Y_base": g.P_Y_base.numpy(),
+        "grid_X_row": g.grid_X[0, 0, :, 0, 0].numpy() if g.grid_X.dim() == 5 else g.grid_X[0, 0, :, 0].numpy(),
+        "grid_Y_col": g.grid_Y[0, :, 0, 0, 0].numpy() if g.grid_Y.dim() == 5 else g.grid_Y[0, :, 0, 0].numpy(),
+        "state_keys": np.array(list(model.state_dict().keys())),
+        "state_shapes": np.array([str(tuple(v.shape)) for v in model.state_dict().values()]),
+    }
+    for k, v in grad_checksums(model).items():
+        data["gcs:" + k] = v
+    np.savez_compressed(os.path.join(out, "warp_model.npz"), **data)
+    print("warp_model.npz loss", data["loss"])
+
+
+def gen_unet(out):
+    from models.unet_mask_model import UnetMaskModel
+
+    for tag, kw in (("plain", dict()), ("gelu", dict(activation="gelu")), ("attn", dict(self_attn=True)),
+                    ("attn_gelu", dict(self_attn=True, activation="gelu"))):
+        hp = hp_namespace(**kw)
+        torch.manual_seed(0)
+        model = UnetMaskModel(hp)
+        model.load_state_dict(procedural_state_dict(shapes_of(model.state_dict())))
+        model.train()
+        batch = synthetic_batch(2, "cpu", smooth=True)
+        res = model.training_step(batch, 0)
+        res.minimize.backward()
+        data = {"state_keys": np.array(list(model.state_dict().keys())),
+                "state_shapes": np.array([str(tuple(v.shape)) for v in model.state_dict().values()])}
+        for k, v in res.logs.items():
+            data["log:" + k] = np.float64(v.item())
+        for name, t in (("p_rendered", model.p_rendereds[0]), ("tryon_mask", model.tryon_masks[0]), ("p_tryon", model.p_tryons[0])):
+            data[name + "_s8"] = strided(t)
+            data[name + "_cs"] = checksums(t)
+        for k, v in grad_checksums(model.unet).items():
+            data["gcs:unet." + k] = v
+        np.savez_compressed(os.path.join(out, f"unet_mask_{tag}.npz"), **data)
+        print(f"unet_mask_{tag}.npz", {k: float(v) for k, v in data.items() if k.startswith("log:")})
+
+
+def gen_ops(out):
+    """Per-op goldens from the reference's nn.Modules at small sizes (full tensors)."""
+    from models.networks.attention.sagan import SelfAttention
+    from models.networks.cpvton.unet import UnetSkipConnectionBlock
+    from models.networks.cpvton.warp import FeatureCorrelation, FeatureL2Norm, TpsGridGen
+
+    rng = np.random.default_rng(7)
+    data = {}
+    # SelfAttention, gamma = 0.7, N = 12 / 48 / 192
+    for (h, w) in ((4, 3), (8, 6), (16, 12)):
+        sa = SelfAttention(64, "relu")
+        sa.load_state_dict(procedural_state_dict(shapes_of(sa.state_dict()), seed=11))
+        x = torch.from_numpy(rng.normal(size=(2, 64, h, w)).astype(np.float32))
+        data[f"sa_x_{h}x{w}"] = x.numpy()
+        data[f"sa_y_{h}x{w}"] = sa(x).detach().numpy()
+    # L2 norm + correlation
+    fa = torch.from_numpy(rng.normal(size=(2, 32, 16, 12)).astype(np.float32))
+    fb = torch.from_numpy(rng.normal(size=(2, 32, 16, 12)).astype(np.float32))
+    na, nb = FeatureL2Norm()(fa), FeatureL2Norm()(fb)
+    data.update(l2_x=fa.numpy(), l2_y=na.numpy(), corr_a=na.numpy(), corr_b=nb.numpy(),
+                corr_y=FeatureCorrelation()(na, nb).contiguous().numpy())
+    # TPS: theta = 0 and random theta
+    tps = TpsGridGen(256, 192, grid_size=5)
+    th = torch.from_numpy((0.3 * rng.uniform(-1, 1, size=(2, 50))).astype(np.float32))
+    data.update(tps_theta=th.numpy(), tps_grid_s4=tps(th)[:, ::4, ::4].contiguous().numpy(),
+                tps_grid0_s4=tps(torch.zeros(1, 50))[:, ::4, ::4].contiguous().numpy())
+    # skip-connection blocks (small C): innermost / middle x {None, gelu}, InstanceNorm
+    for act in (None, "gelu"):
+        inner = UnetSkipConnectionBlock(16, 16, innermost=True, norm_layer=nn.InstanceNorm2d, activation=act)
+        mid = UnetSkipConnectionBlock(8, 16, submodule=inner, norm_layer=nn.InstanceNorm2d, activation=act)
+        mid.load_state_dict(procedural_state_dict(shapes_of(mid.state_dict()), seed=13))
+        x = torch.from_numpy(rng.normal(size=(2, 8, 16, 12)).astype(np.float32))
+        data[f"blk_x_{act}"] = x.numpy()
+        data[f"blk_y_{act}"] = mid(x.clone()).detach().numpy()
+        data[f"blk_keys_{act}"] = np.array(list(mid.state_dict().keys()))
+    np.savez_compressed(os.path.join(out, "ops.npz"), **data)
+    print("ops.npz", len(data), "arrays")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    install_shim()
+    which = sys.argv[1:] or ["ops", "warp", "unet"]
+    if "ops" in which:
+        gen_ops(HERE)
+    if "warp" in which:
+        gen_warp(HERE)
+    if "unet" in which:
+        gen_unet(HERE)

@@ -1,0 +1,199 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/shineon_hip.h declares (no compute
+calls without a GPU); host logic (options, registry, state_dict layout, batch plumbing, PNG wire format,
+optimizer slab bookkeeping, data-parallel reducer over gloo)."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_state, load_golden, make_namespace, oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    from shineon_virtual_tryon_amd import _lib
+
+    protos = _lib.prototypes()
+    assert len(protos) >= 40
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(cdll, name), f"{name} declared in include/shineon_hip.h but not exported"
+    _lib.lib()  # sets argtypes for everything
+
+
+def test_ops_fail_loudly_without_gpu():
+    """No silent CPU fallback: CPU tensors are rejected."""
+    from shineon_virtual_tryon_amd import ops
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(4, 4, 3, 3), None, 1, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.l1_loss(torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "shineon-virtual-tryon_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle/ for", "").replace("see oracle/", ""), f"{f} mentions oracle"
+
+
+def test_options_three_pass_parse_and_fixups():
+    from shineon_virtual_tryon_amd.options import TestOptions, TrainOptions
+
+    opt = TrainOptions().parse(["--model", "gmm", "--dataset", "synthetic", "--name", "t", "--gpu_ids", "0,1", "-b", "4"],
+                               interactive=False)
+    assert opt.model == "warp" and opt.person_inputs == ["agnostic", "cocopose"] and opt.cloth_inputs == ["cloth"]
+    assert opt.gpu_ids == [0, 1] and opt.batch_size == 4 and opt.grid_size == 5 and opt.is_train
+    assert opt.fine_height == 256 and opt.fine_width == 192 and opt.n_frames_now == 1 and opt.lr == 1e-4
+    opt = TrainOptions().parse(["--model", "TOM", "--dataset", "synthetic", "--name", "t", "--self_attn", "--activation",
+                                "gelu", "--person_inputs", "densepose", "agnostic"], interactive=False)
+    assert opt.model == "unet_mask" and opt.person_inputs == ["agnostic", "densepose"]  # SORTED: fixes channel order
+    assert opt.self_attn and opt.num_attn == 2 and opt.pen_flow_mask == 1.0 and opt.activation == "gelu"
+    opt = TestOptions().parse(["--model", "unet", "--dataset", "synthetic", "--name", "t", "--checkpoint", "a/b.ckpt"],
+                              interactive=False)
+    assert not opt.is_train and opt.datamode == "test" and opt.result_dir == "test_results"
+
+
+def test_registry():
+    from shineon_virtual_tryon_amd.registry import find_model_using_name
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    assert find_model_using_name("warp") is WarpModel and find_model_using_name("gmm") is WarpModel
+    assert find_model_using_name("unet_mask") is UnetMaskModel and find_model_using_name("tom") is UnetMaskModel
+    with pytest.raises(NotImplementedError):
+        find_model_using_name("sams")
+
+
+@pytest.mark.parametrize("name,kw", [("warp_model.npz", dict(person_inputs=["agnostic", "cocopose"])),
+                                     ("unet_mask_plain.npz", {}), ("unet_mask_attn_gelu.npz", dict(self_attn=True, activation="gelu"))])
+def test_state_dict_layout_matches_reference(name, kw):
+    """Keys, order and shapes are those of the reference's modules (recorded next to the goldens), so reference
+    checkpoints load with strict=True."""
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    g = load_golden(name)
+    cls = WarpModel if name.startswith("warp") else UnetMaskModel
+    model = cls(make_namespace(**kw))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["state_shapes"]]
+    model.load_state_dict(golden_state(g), strict=True)
+    w = model.state_dict()[[k for k in sd if k.endswith("weight") and sd[k].dim() == 4][0]]
+    assert w.permute(0, 2, 3, 1).is_contiguous()  # OHWI memory behind the (O, I, H, W) shape
+
+
+def test_unet_attention_placement():
+    from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
+    from shineon_virtual_tryon_amd.networks.cpvton.unet import UnetGenerator
+    from shineon_virtual_tryon_amd.networks.layers import HipInstanceNorm2d
+
+    net = UnetGenerator(10, 4, 6, 2, ngf=8, norm_layer=HipInstanceNorm2d, use_self_attn=True, activation="gelu")
+    sas = [n for n, m in net.named_modules() if isinstance(m, SelfAttention)]
+    assert len(sas) == 4 and all("model.1.model.3.model.3.model.3" in n for n in sas)
+    assert oracle.unet_attention_flags(6, 2, True) == [False, False, False, False, True, True]
+
+
+def test_batch_plumbing():
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.tryon_channels import parse_num_channels
+    from shineon_virtual_tryon_amd.util import get_and_cat_inputs, maybe_combine_frames_and_channels
+
+    assert parse_num_channels(["agnostic", "cocopose"]) == 22 and parse_num_channels(["agnostic", "densepose"]) == 7
+    assert parse_num_channels("cloth") == 3
+    b = synthetic_batch(2, "cpu")
+    assert b["agnostic"].shape == (2, 4, 256, 192) and b["cocopose"].shape == (2, 18, 256, 192)
+    assert set(np.unique(b["cloth_mask"].numpy())) <= {0.0, 1.0} and b["image"].abs().max() <= 1
+    b5 = synthetic_batch(2, "cpu", n_frames=3, height=32, width=24)
+    assert b5["image"].shape == (2, 3, 3, 32, 24)
+    hp = argparse.Namespace(n_frames_total=3)
+    c = maybe_combine_frames_and_channels(hp, b5)
+    assert c["image"].shape == (2, 9, 32, 24) and torch.equal(c["image"][:, 3:6], b5["image"][:, 1])
+    cat = get_and_cat_inputs(b, ["agnostic", "cocopose"])
+    assert cat.shape == (2, 22, 256, 192) and torch.equal(cat[:, :4], b["agnostic"])
+    assert torch.equal(synthetic_batch(2, "cpu")["image"], b["image"])  # seed-addressed, reproducible
+
+
+def test_png_wire_format():
+    from shineon_virtual_tryon_amd.io_png import tensor_to_uint8
+
+    t = torch.linspace(-1.2, 1.2, 3 * 8 * 6).reshape(3, 8, 6)
+    assert np.array_equal(tensor_to_uint8(t), oracle.png_quantise(t).swapaxes(0, 1).swapaxes(1, 2))
+    m = torch.tensor([[[-1.0, 0.0, 0.999, 1.0]]])
+    assert tensor_to_uint8(m).tolist() == [[0, 127, 254, 255]]
+
+
+def test_lr_schedule_matches_reference_rule():
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    model = WarpModel(make_namespace(person_inputs=["agnostic", "cocopose"], keep_epochs=2, decay_epochs=3))
+    sched_fn = None
+
+    class FakeOpt(torch.optim.SGD):
+        pass
+
+    opt = FakeOpt([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sched = model._make_step_scheduler(opt)
+    lrs = []
+    for _ in range(6):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    assert np.allclose(lrs, [1, 1, 1, 0.75, 0.5, 0.25])
+
+
+def test_dense_stride_detection():
+    from shineon_virtual_tryon_amd.optim import _is_dense
+
+    assert _is_dense(torch.empty(4, 3, 3, 5).permute(0, 3, 1, 2))
+    assert _is_dense(torch.empty(7)) and not _is_dense(torch.empty(4, 8)[:, :3])
+
+
+_DP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import shineon_virtual_tryon_amd
+from shineon_virtual_tryon_amd.trainer import GradientAllReducer, init_distributed, broadcast_parameters
+rank, world = init_distributed("gloo")
+assert world == 2
+torch.manual_seed(rank)
+flat = torch.full((5000,), float(rank + 1))
+scale = GradientAllReducer(flat, n_buckets=4).all_reduce()
+assert abs(scale - 0.5) < 1e-12 and torch.allclose(flat * scale, torch.full((5000,), 1.5)), flat[:3]
+m = torch.nn.Linear(4, 4)
+broadcast_parameters(m)
+w = [torch.zeros_like(m.weight) for _ in range(2)]
+dist.all_gather(w, m.weight.data)
+assert torch.equal(w[0], w[1])
+# rank r takes samples r::world (DistributedSampler), disjoint and covering
+from torch.utils.data.distributed import DistributedSampler
+idx = list(DistributedSampler(list(range(10)), shuffle=False))
+got = [torch.zeros(5, dtype=torch.long) for _ in range(2)]
+dist.all_gather(got, torch.tensor(idx))
+assert sorted(torch.cat(got).tolist()) == list(range(10))
+dist.barrier()
+print("DP_OK", rank)
+"""
+
+
+def test_data_parallel_reducer_world2_gloo(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP_OK {r}" in o, o

@@ -1,0 +1,173 @@
+"""GPU parity of the two LightningModule-surface models against (a) the golden vectors produced by the
+reference itself and (b) the oracle on the same seeded inputs; plus size-independent properties at
+BASELINE.json's full batch size."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, golden_state, load_golden, make_namespace,
+                     oracle, strided, synthetic_cpu_batch, unet_hp)
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(batch, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+
+
+def _load(model, sd, dev):
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    return model.to(dev)
+
+
+def test_warp_model_vs_reference_golden(cuda):
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    g = load_golden("warp_model.npz")
+    hp = make_namespace(person_inputs=["agnostic", "cocopose"])
+    model = _load(WarpModel(hp), golden_state(g), cuda)
+    assert [k for k in model.state_dict().keys()] == [str(k) for k in g["state_keys"]]
+    model.train()
+    batch = _to(synthetic_cpu_batch(2), cuda)
+    res = model.training_step(batch, 0)
+    res.minimize.backward()
+    person = torch.cat([batch[k] for k in hp.person_inputs], 1)
+    model2 = _load(WarpModel(hp), golden_state(g), cuda).train()
+    with torch.no_grad():
+        grid, theta = model2(person, batch["cloth"])
+    assert_close(theta, g["theta"], atol=2e-5, what="theta")
+    assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")
+    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=2e-3, what="warped cloth")
+    assert abs(res.minimize.item() - float(g["loss"])) < 2e-5
+    gscale = float(np.abs(g["grad_linear_weight"]).max())
+    assert_close(model.regression.linear.weight.grad, g["grad_linear_weight"], atol=3e-3 * gscale, what="d linear.weight")
+    params = dict(model.named_parameters())
+    for k in [k for k in g.files if k.startswith("gcs:")]:
+        assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=k)
+    assert_close(model.extractionA.model[2].running_mean, g["bn_rm_A2"], atol=1e-5, what="BN running mean")
+    assert_close(model.extractionA.model[2].running_var, g["bn_rv_A2"], atol=1e-5, what="BN running var")
+    assert_close(model.regression.conv[10].running_var, g["bn_rv_R10"], atol=1e-4, what="BN running var R10")
+    assert int(model.extractionA.model[2].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("variant", list(UNET_VARIANTS))
+def test_unet_mask_model_vs_reference_golden(cuda, variant):
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+
+    g = load_golden(f"unet_mask_{variant}.npz")
+    hp = make_namespace(**UNET_VARIANTS[variant])
+    model = _load(UnetMaskModel(hp), golden_state(g), cuda)
+    assert [k for k in model.state_dict().keys()] == [str(k) for k in g["state_keys"]]
+    model.train()
+    res = model.training_step(_to(synthetic_cpu_batch(2), cuda), 0)
+    res.minimize.backward()
+    # forward outputs within the north-star tolerance: fp32 atol 1e-4
+    for name, t in (("p_rendered", model.p_rendereds[0]), ("tryon_mask", model.tryon_masks[0]), ("p_tryon", model.p_tryons[0])):
+        assert_close(strided(t), g[name + "_s8"], atol=1e-4, what=f"{variant} {name}")
+        assert_checksums(t, g[name + "_cs"], rel=2e-5, what=f"{variant} {name} checksum")
+    for k in ("loss/G", "loss/G/l1", "loss/G/vgg", "loss/G/tryon_mask_l1", "loss/G/flow_mask_l1"):
+        ref = float(g["log:" + k])
+        assert abs(float(res.logs[k]) - ref) <= 2e-5 + 2e-5 * abs(ref), (k, float(res.logs[k]), ref)
+    params = dict(model.named_parameters())
+    for k in [k for k in g.files if k.startswith("gcs:")]:
+        assert_checksums(params[k[4:]].grad, g[k], rel=1e-2, what=f"{variant} {k}")
+
+
+def test_unet_mask_full_tensor_vs_oracle(cuda):
+    """Every element of the forward outputs and of the input-layer gradient against the oracle (bs=1)."""
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+
+    variant = "attn_gelu"
+    g = load_golden(f"unet_mask_{variant}.npz")
+    sd = golden_state(g)
+    hp = make_namespace(**UNET_VARIANTS[variant])
+    model = _load(UnetMaskModel(hp), sd, cuda).train()
+    batch = synthetic_cpu_batch(1)
+    res = model.training_step(_to(batch, cuda), 0)
+    res.minimize.backward()
+    params = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in sd.items()}
+    out = oracle.unet_mask_losses(params, batch, unet_hp(**UNET_VARIANTS[variant]))
+    out["loss/G"].backward()
+    assert_close(model.p_tryons[0], out["p_tryons"], atol=1e-4, what="p_tryon full")
+    assert_close(model.tryon_masks[0], out["tryon_masks"], atol=1e-4, what="mask full")
+    k0 = "unet.model.model.0.weight"
+    gs = params[k0].grad.abs().max().item()
+    assert_close(dict(model.named_parameters())[k0].grad, params[k0].grad, atol=2e-3 * gs, what="d first conv")
+
+
+def test_warp_full_batch_properties(cuda):
+    """BASELINE bs=4: theta in (-1,1) (tanh), finite grid, identity-grid behaviour when the head is zeroed."""
+    from shineon_virtual_tryon_amd import ops
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    hp = make_namespace(person_inputs=["agnostic", "cocopose"])
+    torch.manual_seed(1)
+    model = WarpModel(hp).to(cuda).train()
+    batch = synthetic_batch(4, cuda)
+    person = torch.cat([batch[k] for k in hp.person_inputs], 1)
+    grid, theta = model(person, batch["cloth"])
+    assert theta.shape == (4, 50) and grid.shape == (4, 256, 192, 2)
+    assert torch.isfinite(grid).all() and theta.abs().max() < 1
+    with torch.no_grad():
+        model.regression.linear.weight.zero_()
+        model.regression.linear.bias.zero_()
+        grid0, theta0 = model(person, batch["cloth"])
+        assert theta0.abs().max() == 0
+        warped = ops.grid_sample(batch["cloth"], grid0, "border")
+    # theta = 0 -> identity warp -> the cloth is reproduced up to the TPS round-off (8e-6 in grid units)
+    smooth = synthetic_batch(4, cuda, smooth=True)["cloth"]
+    with torch.no_grad():
+        assert (ops.grid_sample(smooth, grid0, "border") - smooth).abs().max() < 2e-3
+
+
+def test_training_reduces_loss_and_adam_state(cuda):
+    """A few optimizer steps through HipAdam on the flat slabs: loss goes down, state_dict layout survives."""
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    hp = make_namespace(person_inputs=["agnostic", "cocopose"], lr=1e-3)
+    torch.manual_seed(2)
+    model = WarpModel(hp).to(cuda).train()
+    keys_before = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    (opt,), (sched,) = model.configure_optimizers()
+    batch = synthetic_batch(2, cuda, smooth=True)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        res = model.training_step(batch, 0)
+        res.minimize.backward()
+        opt.step()
+        losses.append(res.minimize.item())
+    assert losses[-1] < losses[0], losses
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == keys_before
+    # parameters are views of one flat slab and gradients of another
+    p = next(model.parameters())
+    assert p.data_ptr() >= opt.flat_params.data_ptr() and p.grad.data_ptr() >= opt.flat_grads.data_ptr()
+
+
+def test_test_step_writes_pngs(cuda, tmp_path):
+    from PIL import Image
+
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    hp = make_namespace(is_train=False, person_inputs=["agnostic", "cocopose"], checkpoint="ckpt/x.ckpt", name="exp",
+                        result_dir=str(tmp_path), datamode="test")
+    model = WarpModel(hp).to(cuda).eval()
+    model.override_hparams(hp)
+    batch = synthetic_batch(2, cuda)
+    batch["dataset_name"] = [["VitonDataset", "VitonDataset"]]  # one list per frame, like the reference's collate
+    names = batch["cloth_name"][0]
+    with torch.no_grad():
+        out = model.test_step(batch, 0)
+    assert out["progress_bar"]["file"] == names[0]
+    d = tmp_path / "exp" / "x.ckpt" / "test" / "VitonDataset"
+    img = np.array(Image.open(d / "warp-cloth" / names[0]))
+    assert img.shape == (256, 192, 3) and img.dtype == np.uint8
+    expected = oracle.png_quantise(model.warped_cloth[0].cpu()).swapaxes(0, 1).swapaxes(1, 2)
+    assert np.array_equal(img, expected)
+    assert (d / "warp-mask" / names[0]).exists()
+    with torch.no_grad():
+        again = model.test_step(batch, 0)
+    assert again["progress_bar"]["file"].startswith("Skipping")

@@ -1,0 +1,162 @@
+"""CPU: the oracle (oracle/shineon_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, golden_state, load_golden, oracle,
+                     strided, synthetic_cpu_batch, unet_hp)
+from oracle.procedural import procedural_state_dict
+
+
+def test_tps_constants_bit_exact():
+    g = load_golden("warp_model.npz")
+    c = oracle.tps_constants(256, 192, 5)
+    # constant base grid / control points: bit-exact (float64 linspace -> fp32)
+    assert np.array_equal(c["gx"].numpy(), g["grid_X_row"])
+    assert np.array_equal(c["gy"].numpy(), g["grid_Y_col"])
+    assert np.array_equal(c["px"].numpy(), g["P_X_base"].reshape(-1))
+    assert np.array_equal(c["py"].numpy(), g["P_Y_base"].reshape(-1))
+    assert_close(c["Li"], g["Li"], atol=1e-5, what="Li")
+
+
+def test_tps_grid_identity_and_random():
+    g = load_golden("ops.npz")
+    c = oracle.tps_constants(256, 192, 5)
+    grid0 = oracle.tps_grid(torch.zeros(1, 50), c)
+    assert_close(grid0[:, ::4, ::4], g["tps_grid0_s4"], atol=1e-5, what="tps theta=0")
+    # known answer: theta = 0 is the identity grid
+    X = c["gx"][None, None, :].expand(1, 256, 192)
+    Y = c["gy"][None, :, None].expand(1, 256, 192)
+    assert_close(grid0, torch.stack([X, Y], 3), atol=2e-5, what="tps identity")
+    grid = oracle.tps_grid(torch.from_numpy(g["tps_theta"]), c)
+    assert_close(grid[:, ::4, ::4], g["tps_grid_s4"], atol=1e-5, what="tps random theta")
+
+
+def test_l2norm_correlation():
+    g = load_golden("ops.npz")
+    assert_close(oracle.feature_l2norm(torch.from_numpy(g["l2_x"])), g["l2_y"], atol=1e-6, what="l2norm")
+    corr = oracle.feature_correlation(torch.from_numpy(g["corr_a"]), torch.from_numpy(g["corr_b"]))
+    assert_close(corr, g["corr_y"], atol=1e-5, what="correlation")
+
+
+def test_correlation_one_hot_known_answer():
+    a = torch.zeros(1, 4, 3, 2)
+    b = torch.zeros(1, 4, 3, 2)
+    a[0, 1, 2, 1] = 1.0  # ia=2, ja=1  -> channel ja*h + ia = 1*3 + 2 = 5
+    b[0, 1, 0, 1] = 2.0
+    corr = oracle.feature_correlation(a, b)
+    assert corr[0, 5, 0, 1] == 2.0 and corr.abs().sum() == 2.0
+
+
+@pytest.mark.parametrize("hw", [(4, 3), (8, 6), (16, 12)])
+def test_self_attention(hw):
+    g = load_golden("ops.npz")
+    h, w = hw
+    x = torch.from_numpy(g[f"sa_x_{h}x{w}"])
+    shapes = {"gamma": (1,), "query_conv.weight": (8, 64, 1, 1), "query_conv.bias": (8,), "key_conv.weight": (8, 64, 1, 1),
+              "key_conv.bias": (8,), "value_conv.weight": (64, 64, 1, 1), "value_conv.bias": (64,)}
+    sd = {"sa." + k: v for k, v in procedural_state_dict(shapes, seed=11).items()}
+    assert_close(oracle.self_attention(x, sd, "sa"), g[f"sa_y_{h}x{w}"], atol=2e-5, what=f"self-attention {hw}")
+
+
+def test_self_attention_gamma_zero_is_identity():
+    shapes = {"gamma": (1,), "query_conv.weight": (8, 64, 1, 1), "query_conv.bias": (8,), "key_conv.weight": (8, 64, 1, 1),
+              "key_conv.bias": (8,), "value_conv.weight": (64, 64, 1, 1), "value_conv.bias": (64,)}
+    sd = {"sa." + k: v for k, v in procedural_state_dict(shapes, seed=11).items()}
+    sd["sa.gamma"] = torch.zeros(1)
+    x = torch.randn(1, 64, 4, 3)
+    assert torch.equal(oracle.self_attention(x, sd, "sa"), x)
+
+
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_skip_block_including_inplace_leaky_quirk(act):
+    g = load_golden("ops.npz")
+    keys = [str(k) for k in g[f"blk_keys_{act}"]]
+    # block tree: mid(8->16) wrapping innermost(16->16); rebuild shapes from the key names
+    shapes = {}
+    for k in keys:
+        if k.startswith("model.3."):  # innermost
+            shapes[k] = (16, 16, 4, 4) if ".1.weight" in k else (16, 16, 3, 3) if k.endswith("weight") else (16,)
+        else:
+            shapes[k] = (16, 8, 4, 4) if k == "model.1.weight" else (8, 32, 3, 3) if k.endswith("weight") else \
+                ((16,) if k == "model.1.bias" else (8,))
+    sd = {"u." + k: v for k, v in procedural_state_dict(shapes, seed=13).items()}
+    x = torch.from_numpy(g[f"blk_x_{act}"])
+    # evaluate with the oracle's recursive U-Net on a 2-level tree: emulate by calling its block logic
+    y = _two_level_block(sd, x, act)
+    assert_close(y, g[f"blk_y_{act}"], atol=2e-5, what=f"skip block act={act}")
+
+
+def _two_level_block(sd, x, act):
+    import torch.nn.functional as F
+
+    down = "leaky" if act is None else act
+    up = "relu" if act is None else act
+    skip0 = x
+    h = oracle.activation(x, down)
+    if act is None:
+        skip0 = h
+    h = F.conv2d(h, sd["u.model.1.weight"], sd["u.model.1.bias"], stride=2, padding=1)
+    h = oracle.instance_norm(h)
+    skip1 = h
+    g_ = oracle.activation(h, down)
+    if act is None:
+        skip1 = g_
+    g_ = F.conv2d(g_, sd["u.model.3.model.1.weight"], sd["u.model.3.model.1.bias"], stride=2, padding=1)
+    g_ = oracle.activation(g_, up)
+    g_ = F.interpolate(g_, scale_factor=2, mode="bilinear", align_corners=False)
+    g_ = oracle.instance_norm(F.conv2d(g_, sd["u.model.3.model.4.weight"], sd["u.model.3.model.4.bias"], padding=1))
+    h = torch.cat([skip1, g_], 1)
+    h = oracle.activation(h, up)
+    h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=False)
+    h = oracle.instance_norm(F.conv2d(h, sd["u.model.6.weight"], sd["u.model.6.bias"], padding=1))
+    return torch.cat([skip0, h], 1)
+
+
+def test_warp_model_training_step():
+    g = load_golden("warp_model.npz")
+    sd = golden_state(g)
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    batch = synthetic_cpu_batch(2)
+    consts = oracle.tps_constants(256, 192, 5)
+    bn = {}
+    out = oracle.warp_losses(params, batch, WARP_HP, consts, bn)
+    assert_close(out["theta"], g["theta"], atol=1e-5, what="theta")
+    assert_close(strided(out["grid"].permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")  # end-to-end: theta error x TPS gain
+    # white-noise cloth: d(sample)/d(grid) ~ 2 * W/2 per unit grid, so the 1e-5 grid tolerance maps to ~3e-3 here
+    assert_close(strided(out["warped_cloth"]), g["warped_cloth_s8"], atol=5e-3, what="warped cloth")
+    assert abs(out["loss/G"].item() - float(g["loss"])) < 1e-5
+    out["loss/G"].backward()
+    # the L1 sign() and the bilinear taps make the loss piecewise: a few samples switch piece under a 1e-5 grid change
+    gscale = float(np.abs(g["grad_linear_weight"]).max())
+    assert_close(params["regression.linear.weight"].grad, g["grad_linear_weight"], atol=2e-3 * gscale, what="d linear.weight")
+    assert_close(params["regression.linear.bias"].grad, g["grad_linear_bias"], atol=2e-3 * float(np.abs(g["grad_linear_bias"]).max()), what="d linear.bias")
+    for k in [k for k in g.files if k.startswith("gcs:")]:
+        assert_checksums(params[k[4:]].grad, g[k], rel=2e-3, what=k)
+    assert_close(bn["extractionA.model.2.running_mean"], g["bn_rm_A2"], atol=1e-6, what="BN running mean")
+    assert_close(bn["extractionA.model.2.running_var"], g["bn_rv_A2"], atol=1e-6, what="BN running var")
+    assert_close(bn["regression.conv.10.running_mean"], g["bn_rm_R10"], atol=1e-5, what="BN running mean R10")
+    assert_close(bn["regression.conv.10.running_var"], g["bn_rv_R10"], atol=1e-5, what="BN running var R10")
+
+
+@pytest.mark.parametrize("variant", list(UNET_VARIANTS))
+def test_unet_mask_training_step(variant):
+    g = load_golden(f"unet_mask_{variant}.npz")
+    sd = golden_state(g)
+    params = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in sd.items()}
+    hp = unet_hp(**UNET_VARIANTS[variant])
+    out = oracle.unet_mask_losses(params, synthetic_cpu_batch(2), hp)
+    for name, key in (("p_rendered", "p_rendereds"), ("tryon_mask", "tryon_masks"), ("p_tryon", "p_tryons")):
+        assert_close(strided(out[key]), g[name + "_s8"], atol=1e-4, what=f"{variant} {name}")
+        assert_checksums(out[key], g[name + "_cs"], rel=1e-5, what=f"{variant} {name} checksum")
+    for k in ("loss/G", "loss/G/l1", "loss/G/vgg", "loss/G/tryon_mask_l1", "loss/G/flow_mask_l1"):
+        assert abs(out[k].item() - float(g["log:" + k])) <= 1e-5 + 1e-5 * abs(float(g["log:" + k])), k
+    out["loss/G"].backward()
+    for k in [k for k in g.files if k.startswith("gcs:")]:
+        assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=f"{variant} {k}")
+
+
+def test_png_quantisation_truncates():
+    t = torch.tensor([[-1.0, -0.999, 0.0, 0.5, 0.9999, 1.0, 1.5]])
+    assert oracle.png_quantise(t).tolist() == [[0, 0, 127, 191, 254, 255, 255]]
