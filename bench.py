@@ -45,12 +45,30 @@ def hparams(**kw):
     return argparse.Namespace(**base)
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup quota, capped at 64
+    (one socket's worth; PyTorch's CPU convolutions stop scaling well before that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(batch_size, iters=2):
     """The oracle (CPU restatement of the reference path) on this host's cores: same chained step."""
     from oracle import shineon_oracle as oracle
     from oracle.procedural import procedural_state_dict, shapes_of
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(usable_cores())
+    log(f"cpu_baseline: {torch.get_num_threads()} threads")
     warp_sd = procedural_state_dict(shapes_of(WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).state_dict()))
     unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).state_dict()))
     wp = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in warp_sd.items()}
@@ -74,14 +92,21 @@ def cpu_baseline(batch_size, iters=2):
         oracle.unet_mask_losses(up, b2, uhp)["loss/G"].backward()
         optu.step()
 
-    step()
     t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    dt = (time.perf_counter() - t0) / iters
+    step()
+    warm = time.perf_counter() - t0
+    log(f"cpu_baseline: warm-up step {warm:.2f} s")
+    if warm > 15.0:  # bounded sample: keep the default run within minutes on a slow host
+        dt, note = warm, "1 chained step (the warm-up itself; host too slow for more)"
+    else:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step()
+        dt = (time.perf_counter() - t0) / iters
+        note = f"1 warm-up + {iters} timed chained steps"
     return {"value": batch_size / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 warm-up + {iters} timed chained steps (WarpModel + UnetMaskModel fwd+bwd+Adam, bs={batch_size}, "
-                      f"256x192) with PyTorch CPU fp32, {dt * 1e3:.0f} ms/step"}
+            "sample": f"{note} (WarpModel + UnetMaskModel fwd+bwd+Adam, bs={batch_size}, 256x192) "
+                      f"with PyTorch CPU fp32, {dt * 1e3:.0f} ms/step"}
 
 
 def main():
@@ -125,8 +150,12 @@ def main():
         res.minimize.backward()
         optu.step(grad_scale=redu.all_reduce())
 
-    for _ in range(args.warmup):
+    log(f"rank {rank}/{world}: models built, warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t_w):.1f} ms")
 
     def fence():
         torch.cuda.synchronize()
@@ -142,6 +171,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     L.so_prof_enable(0)
+    log(f"timed {args.steps} steps: {1e3 * elapsed / args.steps:.2f} ms/step")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

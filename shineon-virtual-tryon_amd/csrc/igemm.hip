@@ -71,7 +71,13 @@ __device__ __forceinline__ void so_row_offset(const SoIgemm& p, int cls, int m, 
       const int rem = m - n * hw2;
       const int h2 = rem / p.W2;
       const int w2 = rem - h2 * p.W2;
-      const long long pix = ((long long)n * p.H + (h2 * p.stride + ph)) * p.W + (w2 * p.stride + pw);
+      const int hi = h2 * p.stride + ph, wi = w2 * p.stride + pw;
+      if (hi >= p.H || wi >= p.W) {  // ragged class grid (H or W not a multiple of the stride)
+        off = -1;
+        roff = 0;
+        return;
+      }
+      const long long pix = ((long long)n * p.H + hi) * p.W + wi;
       off = pix * p.ldc;
       roff = pix * p.ldres;
       return;
@@ -159,9 +165,12 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
           const int rem = m - n * hw2;
           const int h2 = rem / p.W2;
           const int w2 = rem - h2 * p.W2;
-          a_base[j] = n * p.Ho;
-          a_h0[j] = h2 + d_oh;
-          a_w0[j] = w2 + d_ow;
+          const int ph_ = cls / p.stride, pw_ = cls - ph_ * p.stride;
+          if (h2 * p.stride + ph_ < p.H && w2 * p.stride + pw_ < p.W) {
+            a_base[j] = n * p.Ho;
+            a_h0[j] = h2 + d_oh;
+            a_w0[j] = w2 + d_ow;
+          }
         } else {  // GEMM KC
           a_base[j] = m;
           a_h0[j] = 0;
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
       } else {
         long long off, roff;
         so_row_offset<MODE>(p, cls, m, off, roff);
+        if (off < 0) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn * WTN + j * 32 + li;
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
     for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * mn];
     long long off, roff;
     so_row_offset<MODE>(p, cls, m, off, roff);
+    if (off < 0) continue;
     p.c[off + n] = so_epilogue(p, v, roff, n);
   }
 }
@@ -593,14 +604,14 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                     long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || (C & 3) || !so_aligned16(dy) || !so_aligned16(w)) return SO_ERR_ALIGN;
-  if ((R % stride) || (S % stride) || (H % stride) || (W % stride)) return SO_ERR_SHAPE;
+  if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
   SoIgemm p = {};
   p.a = dy; p.b = w; p.c = dx; p.ws = ws;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
   p.Ho = (H + 2 * pad - R) / stride + 1;
   p.Wo = (W + 2 * pad - S) / stride + 1;
   p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.TS = S / stride; p.H2 = H / stride; p.W2 = W / stride;
+  p.TS = S / stride; p.H2 = (H + stride - 1) / stride; p.W2 = (W + stride - 1) / stride;
   p.nclass = stride * stride;
   p.M = Nb * p.H2 * p.W2; p.N = C; p.K = (R / stride) * (S / stride) * Ko;
   p.lda = lddy; p.ldb = C; p.ldc = lddx; p.ldres = 0;

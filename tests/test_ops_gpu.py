@@ -19,7 +19,7 @@ def ops(cuda):
 
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
-    return torch.randn(*shape, generator=g) * scale
+    return torch.randn(tuple(shape), generator=g) * scale
 
 
 def grads(outs, inputs, seeds):
@@ -28,7 +28,7 @@ def grads(outs, inputs, seeds):
     return torch.autograd.grad(loss, inputs, allow_unused=True)
 
 
-def compare_fwd_bwd(hip_fn, ref_fn, inputs, cuda, atol=1e-4, rtol=1e-4, gatol=None, what=""):
+def compare_fwd_bwd(hip_fn, ref_fn, inputs, cuda, atol=1e-4, rtol=1e-4, gatol=None, what="", grel=None):
     """inputs: list of (tensor, requires_grad).  Functions return a tensor or tuple of tensors."""
     gatol = atol if gatol is None else gatol
     cpu_in = [t.clone().requires_grad_(rg) for t, rg in inputs]
@@ -46,7 +46,9 @@ def compare_fwd_bwd(hip_fn, ref_fn, inputs, cuda, atol=1e-4, rtol=1e-4, gatol=No
     gr = grads(r, need, seeds)
     gh = grads(h, [x for x, (_, rg) in zip(gpu_in, inputs) if rg], [s.to(cuda) for s in seeds])
     for i, (a, b) in enumerate(zip(gh, gr)):
-        assert_close(a, b, atol=gatol, rtol=rtol, what=f"{what} grad[{i}]")
+        # grel: tolerance relative to the largest reference gradient entry (long reductions, e.g. TPS over H*W)
+        tol = gatol if grel is None else grel * b.abs().max().item()
+        assert_close(a, b, atol=tol, rtol=rtol, what=f"{what} grad[{i}]")
 
 
 # ------------------------------------------------------------------------------------------------ conv
@@ -234,7 +236,7 @@ def test_tps_grid(ops, cuda, hw):
     c, dev = _tps_consts(cuda, h, w, 5)
     theta = rnd(2, 50, seed=35, scale=0.15)
     compare_fwd_bwd(lambda t: ops.tps_grid(t, dev, h, w, 25), lambda t: oracle.tps_grid(t, c), [(theta, True)], cuda,
-                    atol=1e-5, gatol=2e-3, rtol=1e-4, what="tps")
+                    atol=1e-5, grel=1e-3, rtol=1e-4, what="tps")  # fp32 sums over 49152 pixels, different order
     # known answer: theta = 0 -> identity grid (base grid exactly, up to fp32 round-off of the affine part)
     g0 = ops.tps_grid(torch.zeros(1, 50, device=cuda), dev, h, w, 25).cpu()
     X, Y = c["gx"][None, None, :].expand(1, h, w), c["gy"][None, :, None].expand(1, h, w)
@@ -288,7 +290,7 @@ def test_l1_loss(ops, cuda):
     a, b = rnd(2, 3, 32, 24, seed=43), rnd(2, 3, 32, 24, seed=44)
     compare_fwd_bwd(lambda p, q: ops.l1_loss(p, q), lambda p, q: F.l1_loss(p, q), [(a, True), (b, False)], cuda,
                     atol=1e-6, gatol=1e-9, what="l1 planar")
-    compare_fwd_bwd(lambda p, q: ops.l1_loss(ops.to_rows(p), q, 0.25), lambda p, q: 0.25 * F.l1_loss(p, q),
+    compare_fwd_bwd(lambda p, q: ops.l1_loss(ops.activation(p, None), q, 0.25), lambda p, q: 0.25 * F.l1_loss(p, q),
                     [(a, True), (b, False)], cuda, atol=1e-6, gatol=1e-9, what="l1 rows")
     assert ops.l1_loss(a.to(cuda), a.to(cuda)).item() == 0.0
 
