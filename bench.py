@@ -34,7 +34,7 @@ from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel  # noqa: E40
 from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
-KEY_NAMES = ["fprop64", "fprop128", "dgrad64", "dgrad128", "wgrad64", "wgrad128", "gemm64", "gemm128"]
+KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm") for t in ("64x64", "128x64", "64x128", "128x128")]
 
 
 def hparams(**kw):
@@ -177,16 +177,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms = (ctypes.c_float * 8)()
-    fl = (ctypes.c_float * 8)()
-    cnt = (ctypes.c_int * 8)()
+    ms = (ctypes.c_float * 16)()
+    fl = (ctypes.c_float * 16)()
+    cnt = (ctypes.c_int * 16)()
     L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
 
     if rank == 0:
         kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / args.steps,
                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
-                   for k in range(8) if cnt[k] > 0}
-        dom = max(range(8), key=lambda k: ms[k])
+                   for k in range(16) if cnt[k] > 0}
+        dom = max(range(16), key=lambda k: ms[k])
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         mfma_ms = sum(ms) / args.steps
         out = {

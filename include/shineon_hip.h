@@ -61,12 +61,14 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
                     const float* res, int ldres, long long sres, int act, float act_param,
                     float* ws, long long ws_bytes, void* stream);
 
-/* test hook: force the block tile (128 / 64, 0 = auto) and split-K factor (0 = auto). */
-void so_igemm_force(int bm, int splitk);
+/* test / tuning hooks: force the block tile (bm, bn in {64, 128}; bm = 0 -> auto) and the split-K factor
+ * (0 = auto); set the per-FLOP cost factors of the four tile shapes used by the tile planner. */
+void so_igemm_force(int bm, int bn, int splitk);
+void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x128);
 
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
- * stream.  so_prof_collect waits for them and fills HOST arrays of 8 entries, key = mode*2 + (tile==128)
- * with mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm: summed milliseconds, summed algorithmic FLOPs
+ * stream.  so_prof_collect waits for them and fills HOST arrays of 16 entries, key = mode*4 + tile
+ * (mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm; tile 0 64x64, 1 128x64, 2 64x128, 3 128x128): summed milliseconds, summed algorithmic FLOPs
  * (2*M*N*K per launch), launch count.  Returns the number of launches collected and clears the list. */
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);

@@ -329,10 +329,18 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
 __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ part, unsigned nchunk,
                                                       unsigned C, float* __restrict__ out,
                                                       int accumulate) {
-  const unsigned c = blockIdx.x * 256u + threadIdx.x;
-  if (c >= C) return;
+  // 16 columns x 16 chunk-lanes per block, lanes merged in fixed order (deterministic)
+  __shared__ float sh[256];
+  const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const unsigned c = blockIdx.x * 16u + tx;
   float s = 0.f;
-  for (unsigned k = 0; k < nchunk; ++k) s += part[(size_t)k * C + c];
+  if (c < C)
+    for (unsigned k = ty; k < nchunk; k += 16) s += part[(size_t)k * C + c];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  s = 0.f;
+  for (unsigned l = 0; l < 16; ++l) s += sh[l * 16 + tx];
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -654,7 +662,7 @@ int so_colsum(const float* x, int ldx, long long rows, int C, float* out, int ac
   dim3 grid(nchunk, so_cdiv(C, CPB));
   hipLaunchKernelGGL(colsum_partial_k, grid, dim3(256), 0, st, x, ldx, (unsigned)rows, (unsigned)C,
                      chunk, ws);
-  hipLaunchKernelGGL(colsum_final_k, dim3(so_cdiv(C, 256)), dim3(256), 0, st, ws, nchunk, (unsigned)C,
+  hipLaunchKernelGGL(colsum_final_k, dim3(so_cdiv(C, 16)), dim3(256), 0, st, ws, nchunk, (unsigned)C,
                      out, accumulate);
   return SO_LAUNCH_CHECK();
 }

@@ -444,47 +444,54 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
 // Host side: tile / split-K selection and launch.
 // ------------------------------------------------------------------------------------------------
 struct SoPlan {
-  int bm, splitk, ktps;
+  int bm, bn, splitk, ktps;
 };
 
-static SoPlan so_plan(const SoIgemm& p, long long ws_floats, int force_bm, int force_splitk) {
+// Tile shapes compiled for every mode.  Per-FLOP cost factors relative to 128x128 come from the
+// igemm micro-benchmark (tools/igemm_bench.py); the model is: blocks are dealt round-robin to 256 CUs, a CU's
+// time is (#blocks it owns) x (K tiles per block + prologue/epilogue) x (tile FLOPs / per-CU MFMA rate).
+static const int kTiles[4][2] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
+// Measured (profiles/r01_igemm_microbench.csv): at the hot path's 1-15 GFLOP layer sizes the 64x64 tile is the
+// most robust (4 blocks/CU hide the per-K-tile staging bubble); the wider tiles only win when they remove a
+// quantisation step, so they carry a penalty.
+static double g_tile_cost[4] = {1.0, 1.12, 1.15, 1.2};
+
+static int g_force_bm = 0, g_force_bn = 0, g_force_splitk = 0;
+
+static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
   const int nkt = so_cdiv(p.K, 32);
-  SoPlan best = {64, 1, nkt};
+  SoPlan best = {64, 64, 1, nkt};
   double best_cost = 1e30;
-  const int bms[2] = {128, 64};
-  for (int bi = 0; bi < 2; ++bi) {
-    const int bm = bms[bi];
-    if (force_bm && bm != force_bm) continue;
-    const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bm) * p.nclass;
-    for (int sk = 1; sk <= 256; sk *= 2) {
-      if (force_splitk && sk != force_splitk) continue;
+  for (int ti = 0; ti < 4; ++ti) {
+    const int bm = kTiles[ti][0], bn = kTiles[ti][1];
+    if (g_force_bm && (bm != g_force_bm || bn != g_force_bn)) continue;
+    const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bn) * p.nclass;
+    for (int sk = 1; sk <= 512; sk *= 2) {
+      if (g_force_splitk && sk != g_force_splitk) continue;
       if (sk > nkt) break;
       const int ktps = so_cdiv(nkt, sk);
       const int sk_eff = so_cdiv(nkt, ktps);
       if (sk_eff > 1 && (long long)sk_eff * p.nclass * p.M * p.N > ws_floats) continue;
       const long long blocks = tiles * sk_eff;
-      // per-CU MFMA time for one K tile of this block shape (0.6 TFLOP/s per CU at ~75 %)
-      const double t_kt = 2.0 * bm * bm * 32 / (0.6e12 * 0.75) * (bm == 64 ? 1.12 : 1.0);
+      const double t_kt = 2.0 * bm * bn * 32 / (0.6e12 * 0.8) * g_tile_cost[ti];
       const double waves = (double)((blocks + 255) / 256);
       double cost = waves * (ktps + 3) * t_kt;
       if (sk_eff > 1) cost += 3e-6 + (double)(sk_eff + 1) * p.nclass * p.M * p.N * 4.0 / 3e12;
       if (cost < best_cost) {
         best_cost = cost;
-        best = {bm, sk_eff, ktps};
+        best = {bm, bn, sk_eff, ktps};
       }
     }
   }
   return best;
 }
 
-static int g_force_bm = 0, g_force_splitk = 0;
-
 // ---- optional live timing of every MFMA launch with HIP events (bench.py's roofline figure) --------
 // Events are recorded on the launch stream around the main kernel only (not the split-K reduce).
 #include <vector>
 struct SoProfRec {
   hipEvent_t e0, e1;
-  int key;  // MODE * 2 + (BM == 128)
+  int key;  // MODE * 4 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128)
   double flops;
 };
 static bool g_prof_on = false;
@@ -497,17 +504,17 @@ static hipEvent_t so_prof_event() {
     g_prof_pool.pop_back();
     return e;
   }
-  hipEvent_t e;
-  hipEventCreate(&e);
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
   return e;
 }
 
-template <int MODE, bool A_MC, bool B_MC, int BM>
+template <int MODE, bool A_MC, bool B_MC, int BM, int BN>
 static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   constexpr int A_STAGE = A_MC ? 32 * BM : BM * 36;
-  constexpr int B_STAGE = B_MC ? 32 * BM : BM * 36;
+  constexpr int B_STAGE = B_MC ? 32 * BN : BN * 36;
   constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
-  auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BM>;
+  auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -515,19 +522,19 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BM);
+  const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(p.nclass * p.splitk));
   SoProfRec rec;
   if (g_prof_on) {
     rec.e0 = so_prof_event();
     rec.e1 = so_prof_event();
-    rec.key = MODE * 2 + (BM == 128 ? 1 : 0);
+    rec.key = MODE * 4 + (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0);
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
-    hipEventRecord(rec.e0, stream);
+    (void)hipEventRecord(rec.e0, stream);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
   if (g_prof_on) {
-    hipEventRecord(rec.e1, stream);
+    (void)hipEventRecord(rec.e1, stream);
     g_prof.push_back(rec);
   }
   int err = SO_LAUNCH_CHECK();
@@ -545,29 +552,36 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
 template <int MODE, bool A_MC, bool B_MC>
 static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return 0;
-  const SoPlan plan = so_plan(p, p.ws ? ws_bytes / 4 : 0, g_force_bm, g_force_splitk);
+  const SoPlan plan = so_plan(p, p.ws ? ws_bytes / 4 : 0);
   p.splitk = plan.splitk;
   p.ktps = plan.ktps;
-  if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128>(p, stream);
-  return so_launch_tile<MODE, A_MC, B_MC, 64>(p, stream);
+  if (plan.bm == 128 && plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 128>(p, stream);
+  if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 64>(p, stream);
+  if (plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 64, 128>(p, stream);
+  return so_launch_tile<MODE, A_MC, B_MC, 64, 64>(p, stream);
 }
 
 static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
 
-void so_igemm_force(int bm, int splitk) {
+void so_igemm_force(int bm, int bn, int splitk) {
   g_force_bm = bm;
+  g_force_bn = bn;
   g_force_splitk = splitk;
+}
+
+void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x128) {
+  g_tile_cost[0] = c64x64; g_tile_cost[1] = c128x64; g_tile_cost[2] = c64x128; g_tile_cost[3] = c128x128;
 }
 
 void so_prof_enable(int on) { g_prof_on = on != 0; }
 
-// Waits for every recorded launch, then fills per-key totals (key = mode*2 + (tile==128), 8 keys):
+// Waits for every recorded launch, then fills per-key totals (key = mode*4 + tile index, 16 keys):
 // out_ms[k] = summed kernel time in ms, out_flops[k] = summed algorithmic FLOPs, out_count[k] = launches.
 // Clears the record list.  Returns the number of launches collected.
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
-  for (int k = 0; k < 8; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
+  for (int k = 0; k < 16; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
   int n = 0;
   for (auto& r : g_prof) {
     float ms = 0.f;

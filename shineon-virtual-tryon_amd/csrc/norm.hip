@@ -83,14 +83,24 @@ __global__ __launch_bounds__(256) void stats_final_k(const float* __restrict__ p
                                                      float* __restrict__ rstd,
                                                      float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum) {
-  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  // 16 columns x 16 chunk-lanes per block: lane l merges chunks l, l+16, ... then the lanes are merged in
+  // a fixed order through LDS (deterministic).
+  __shared__ float sn[256], sm[256], s2[256];
+  const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
-  if (c >= C) return;
   Mom acc = {0.f, 0.f, 0.f};
-  for (unsigned k = 0; k < nchunk; ++k) {
-    const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
-    acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
+  if (c < C) {
+    for (unsigned k = ty; k < nchunk; k += 16) {
+      const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
+      acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
+    }
   }
+  sn[threadIdx.x] = acc.n; sm[threadIdx.x] = acc.mean; s2[threadIdx.x] = acc.m2;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  acc = Mom{0.f, 0.f, 0.f};
+  for (unsigned l = 0; l < 16; ++l) acc = mom_merge(acc, Mom{sn[l * 16 + tx], sm[l * 16 + tx], s2[l * 16 + tx]});
   const float var = acc.m2 / acc.n;
   mean[(size_t)g * C + c] = acc.mean;
   rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
@@ -174,14 +184,22 @@ __global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict_
                                                         float* __restrict__ sums,
                                                         float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta) {
-  const unsigned c = blockIdx.x * 256u + threadIdx.x;
+  __shared__ float sa[256], sb[256];
+  const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
-  if (c >= C) return;
   float a = 0.f, b = 0.f;
-  for (unsigned k = 0; k < nchunk; ++k) {
-    const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
-    a += o[c]; b += o[C + c];
+  if (c < C) {
+    for (unsigned k = ty; k < nchunk; k += 16) {
+      const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
+      a += o[c]; b += o[C + c];
+    }
   }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  a = 0.f; b = 0.f;
+  for (unsigned l = 0; l < 16; ++l) { a += sa[l * 16 + tx]; b += sb[l * 16 + tx]; }
   sums[(size_t)g * 2 * C + c] = a;
   sums[(size_t)g * 2 * C + C + c] = b;
   if (dgamma) { dgamma[c] = b; dbeta[c] = a; }
@@ -230,6 +248,9 @@ inline void chunking(long long R, int C, unsigned& chunk, unsigned& nchunk) {
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   const unsigned RL = 256 / CPB;
   chunk = EPT * RL;
+  // keep the number of partial blocks per column tile around 256 (enough to fill the chip, cheap to merge)
+  const unsigned min_chunk = (unsigned)((R + 255) / 256);
+  if (chunk < min_chunk) chunk = (min_chunk + RL - 1) / RL * RL;
   nchunk = (unsigned)((R + chunk - 1) / chunk);
 }
 
@@ -256,7 +277,7 @@ int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, 
   dim3 g1(nchunk, so_cdiv(C, CPB), G);
   hipLaunchKernelGGL(stats_partial_k, g1, dim3(256), 0, st, x, ldx, (unsigned)R, (unsigned)C, chunk,
                      nchunk, ws);
-  dim3 g2(so_cdiv(C, 256), G);
+  dim3 g2(so_cdiv(C, 16), G);
   hipLaunchKernelGGL(stats_final_k, g2, dim3(256), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
                      running_mean, running_var, momentum);
   const long long total = (long long)G * R * C;
@@ -296,7 +317,7 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
   dim3 g1(nchunk, so_cdiv(C, CPB), G);
   hipLaunchKernelGGL(norm_bwd_partial_k, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
                      (unsigned)C, chunk, nchunk, mean, rstd, part);
-  dim3 g2(so_cdiv(C, 256), G);
+  dim3 g2(so_cdiv(C, 16), G);
   hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(256), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
                      dbeta);
   const long long total = (long long)G * R * C;

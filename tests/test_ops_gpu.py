@@ -65,7 +65,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("force", [(0, 0), (128, 1), (64, 1), (64, 4), (128, 2)])
+@pytest.mark.parametrize("force", [(0, 0, 0), (128, 128, 1), (64, 64, 1), (64, 64, 4), (128, 128, 2), (128, 64, 1), (64, 128, 2)])
 def test_conv2d_fwd_bwd(ops, cuda, case, force):
     from shineon_virtual_tryon_amd import lib
 
@@ -82,7 +82,7 @@ def test_conv2d_fwd_bwd(ops, cuda, case, force):
             what=f"conv {case} force={force}",
         )
     finally:
-        lib().so_igemm_force(0, 0)
+        lib().so_igemm_force(0, 0, 0)
 
 
 def test_conv2d_fused_relu(ops, cuda):
