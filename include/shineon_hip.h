@@ -52,6 +52,11 @@ int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* d
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                     long long ws_bytes, void* stream);
 
+/* same, accumulating: dw += ... (writes straight into the flat gradient slab the optimizer owns) */
+int so_conv2d_wgrad_acc(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,
+                        int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                        long long ws_bytes, void* stream);
+
 /* torch.bmm replacement (sagan.py:44,50; warp.py:63):
  * C[b] = act(alpha[0] * opA(A[b]) opB(B[b]) + bias[n] + res[b]),  alpha/bias/res optional (NULL).
  * transa 0: A [M][K]; 1: A [K][M].  transb 0: B [K][N]; 1: B [N][K].  (transa=1,transb=1 unsupported) */

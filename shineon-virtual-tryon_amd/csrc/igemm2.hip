@@ -1,33 +1,37 @@
-// fp32 MFMA implicit-GEMM engine for gfx950 (MI355X).
+// fp32 MFMA implicit-GEMM engine for gfx950 (MI355X), second structure.
 //
 // One kernel template covers every contraction on the try-on hot path:
 //   FPROP : y[pix][ko]      = sum_{r,s,c} x[pix@(r,s)][c] * w[ko][r][s][c]      (Conv2d forward)
-//   DGRAD : dx[pix][c]      = sum_{r,s,ko} dy[pix'@(r,s)][ko] * w[ko][r][s][c]  (Conv2d input gradient,
+//   DGRAD : dx[pix][c]      = sum_{r,s,ko} dy[pix'@(r,s)][ko] * w[ko][r][s][c]  (Conv2d input gradient;
 //                             strided convs are split in stride^2 parity classes so no zero taps are multiplied)
 //   WGRAD : dw[ko][r][s][c] = sum_{pix} dy[pix][ko] * x[pix@(r,s)][c]           (Conv2d weight gradient)
-//   GEMM  : batched C = op(A) op(B) for attention (QK^T, AV and their gradients) and the
-//           feature-correlation volume.
+//   GEMM  : batched C = op(A) op(B) for attention (QK^T, AV and their gradients) and the correlation volume.
 // Reference ops replaced: torch conv2d / bmm as used by models/networks/cpvton/unet.py:129-174,
 // models/networks/cpvton/warp.py:9-99, models/networks/attention/sagan.py:38-50, models/networks/vgg.py:6-36.
 //
 // Design (CDNA4):
-//   * activations NHWC, weights OHWI  -> the GEMM K axis (channels within a filter tap) is contiguous in
-//     HBM for both operands: every global load is a 16-byte quad, 8 lanes cover one 128-byte line.
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  K may be permuted freely as long as A and B
-//     agree, so a lane-half reads FOUR consecutive k with one ds_read_b128 and feeds four MFMAs
+//   * activations NHWC, weights OHWI -> the GEMM K axis (channels within a filter tap) is contiguous in HBM for
+//     both operands: every global load is a 16-byte quad, 8 lanes cover one 128-byte line.
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  K may be permuted freely as long as A and B agree,
+//     so a lane-half reads FOUR consecutive k with one ds_read_b128 and feeds four MFMAs
 //     (k = kbase + 4*(lane>>5) + t for MFMA t).
 //   * two operand staging modes in LDS:
-//       KC ("k-contiguous")  : tile [rows][32 k] with row stride 36 floats -> conflict-free ds_read_b128
-//       MC ("mn-contiguous") : tile [32 k][rows]                          -> conflict-free ds_read_b32
+//       KC ("k-contiguous")  : tile [rows][32 k], row pitch 36 floats -> conflict-free ds_read_b128
+//       MC ("mn-contiguous") : tile [32 k][rows]                      -> conflict-free ds_read_b32
 //     FPROP = KC x KC, DGRAD = KC x MC (weights read in place, no transposed copy), WGRAD = MC x MC.
-//   * 256 threads = 4 waves (2x2), block tile 128x128 or 64x64, BK = 32, double-buffered LDS with the
-//     next tile's global loads in flight in registers while the current tile is multiplied
-//     (one barrier per K tile).
-//   * deterministic split-K (slabs in a workspace + reduce kernel carrying the fused epilogue) for the
-//     tiny-spatial layers and for WGRAD, where the reduction axis is the pixel count.
+//   * BRANCH-FREE staging: operands are read through buffer descriptors; a lane that must see a zero (conv
+//     padding, ragged tile edge, K tail) issues the same buffer_load with an out-of-range offset and the
+//     hardware returns 0.  The K-tile body is one straight-line block, so the scheduler can slot the address
+//     arithmetic, the ds_writes and the next loads into the 64-cycle shadows of the fp32 MFMAs.
+//   * software pipeline, prefetch distance 2: while tile t is multiplied, tile t+1 is written to the other LDS
+//     buffer (its loads were issued during tile t-1) and the loads of tile t+2 are issued; one barrier per tile.
+//   * index decode (k -> tap/channel, pixel -> n/h/w) uses a reciprocal-multiply division (operands < 2^24).
+//   * 256 threads = 4 waves (2x2); block tiles 64x64, 128x64, 64x128, 128x128; BK = 32.
+//   * deterministic split-K (slabs in a workspace + reduce kernel carrying the fused epilogue).
 //   * fused epilogue: alpha (device scalar, attention gamma) * acc + bias[n] + residual, then activation.
 #include "common.h"
 #include "../../include/shineon_hip.h"
+#include <vector>
 
 enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_GEMM = 3 };
 
@@ -39,18 +43,34 @@ struct SoIgemm {
   const float* bias;
   const float* alpha;
   const float* res;
+  unsigned a_bytes, b_bytes;  // buffer extents for the descriptors (per batch matrix in GEMM mode)
   int M, N, K;
   int lda, ldb, ldc, ldres;
   int Nb, H, W, C;   // input-side tensor (x / dx)
   int Ho, Wo, Ko;    // output-side tensor (y / dy)
   int R, S, stride, pad;
   int TS;            // DGRAD: taps per class along W (= S / stride)
-  int H2, W2;        // DGRAD: class grid (= H / stride, W / stride)
+  int H2, W2;        // DGRAD: class grid (= ceil(H / stride), ceil(W / stride))
   int act;
   float act_param;
   int splitk, ktps, nclass;
   long long sa, sb, sc, sres;  // GEMM batch strides in elements
 };
+
+#define SO_OOB 0x80000000u  // byte offset beyond any operand (< 2 GiB each): buffer_load returns 0
+
+// floor(x / d) and x % d for 0 <= x < 2^24, d >= 1, with inv = 1.0f / d: one multiply + one correction step.
+__device__ __forceinline__ void so_divmod(unsigned x, unsigned d, float inv, unsigned& q, unsigned& r) {
+  q = (unsigned)(__uint2float_rz(x) * inv);
+  int rem = (int)x - (int)(q * d);
+  const int neg = rem < 0 ? 1 : 0;   // branch-free corrections (selects)
+  q -= (unsigned)neg;
+  rem += neg ? (int)d : 0;
+  const int big = rem >= (int)d ? 1 : 0;
+  q += (unsigned)big;
+  rem -= big ? (int)d : 0;
+  r = (unsigned)rem;
+}
 
 __device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long long res_off, int n) {
   if (p.alpha) v *= p.alpha[0];
@@ -59,7 +79,7 @@ __device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long lon
   return so_actf(p.act, v, p.act_param);
 }
 
-// Row index of the GEMM -> element offset of that output row (and of the residual row).
+// Row index of the GEMM -> element offset of that output row (and of the residual row); off < 0: skip the row.
 template <int MODE>
 __device__ __forceinline__ void so_row_offset(const SoIgemm& p, int cls, int m, long long& off,
                                               long long& roff) {
@@ -93,16 +113,26 @@ __device__ __forceinline__ void so_row_offset(const SoIgemm& p, int cls, int m, 
   }
 }
 
+typedef int so_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 so_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  const so_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+  f32x4 r;
+  r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]);
+  r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
+  return r;
+}
+
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
-  constexpr int LDK = 36;  // KC row stride: 144 B -> 16 lanes of a ds_read_b128 group hit 16 distinct slots
+  constexpr int LDK = 36;  // KC row pitch: 144 B -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots
   constexpr int A_STAGE = A_MC ? BK * BM : BM * LDK;
   constexpr int B_STAGE = B_MC ? BK * BN : BN * LDK;
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AJ = BM / 32, BJ = BN / 32;  // 16-byte quads staged per thread per K tile
-  constexpr int AQPR = BM / 4, BQPR = BN / 4;  // MC mode: quads per k-row
+  constexpr int AJ = BM / 32, BJ = BN / 32;            // 16-byte quads staged per thread per K tile
+  constexpr int AQPR = BM / 4, BQPR = BN / 4;          // MC mode: quads per k-row
   constexpr int ARPP = 256 / AQPR, BRPP = 256 / BQPR;  // MC mode: k-rows covered per pass
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -121,12 +151,14 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
   const int cls = blockIdx.z / p.splitk;
   const int split = blockIdx.z - cls * p.splitk;
 
-  const float* __restrict__ gA = p.a;
-  const float* __restrict__ gB = p.b;
+  const float* gA = p.a;
+  const float* gB = p.b;
   if constexpr (MODE == MODE_GEMM) {
     gA += (long long)cls * p.sa;
     gB += (long long)cls * p.sb;
   }
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, (int)p.b_bytes, 0x00020000);
 
   // DGRAD parity class constants
   int d_r0 = 0, d_s0 = 0, d_oh = 0, d_ow = 0;
@@ -138,17 +170,23 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
     d_ow = (pw + p.pad - d_s0) / p.stride;
   }
 
-  // ---------------- per-thread loader state -----------------
-  const int kq = tid & 7;        // KC: quad within the 32-wide k row
-  const int krow8 = tid >> 3;    // KC: row within a 32-row pass
-  // A operand
-  int a_base[AJ], a_h0[AJ], a_w0[AJ];
-  (void)a_base; (void)a_h0; (void)a_w0;
+  // reciprocals for the index decodes (all dividends < 2^24)
+  const float invC = 1.0f / (float)(p.C > 0 ? p.C : 1), invS = 1.0f / (float)(p.S > 0 ? p.S : 1);
+  const float invKo = 1.0f / (float)(p.Ko > 0 ? p.Ko : 1), invTS = 1.0f / (float)(p.TS > 0 ? p.TS : 1);
+  const float invWo = 1.0f / (float)(p.Wo > 0 ? p.Wo : 1);
+  const float invHWo = 1.0f / (float)(p.Ho * p.Wo > 0 ? p.Ho * p.Wo : 1);
+
+  // ---------------- per-thread loader state (K-tile invariant) -----------------
+  const int kq = tid & 7;      // KC: quad within the 32-wide k row
+  const int krow8 = tid >> 3;  // KC: row within a 32-row pass
+  // A operand, KC: element offset of the row's origin pixel and its (h0, w0); invalid rows get h0 = -2^28
+  int a_org[AJ], a_h0[AJ], a_w0[AJ];
+  (void)a_org; (void)a_h0; (void)a_w0;
   if constexpr (!A_MC) {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int m = m0 + krow8 + 32 * j;
-      a_base[j] = 0; a_h0[j] = -(1 << 28); a_w0[j] = 0;
+      a_org[j] = 0; a_h0[j] = -(1 << 28); a_w0[j] = 0;
       if (m < p.M) {
         if constexpr (MODE == MODE_FPROP) {
           const int hw = p.Ho * p.Wo;
@@ -156,9 +194,9 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
           const int rem = m - n * hw;
           const int ho = rem / p.Wo;
           const int wo = rem - ho * p.Wo;
-          a_base[j] = n * p.H;
           a_h0[j] = ho * p.stride - p.pad;
           a_w0[j] = wo * p.stride - p.pad;
+          a_org[j] = ((n * p.H + a_h0[j]) * p.W + a_w0[j]) * p.lda;  // may be negative; only used when in range
         } else if constexpr (MODE == MODE_DGRAD) {
           const int hw2 = p.H2 * p.W2;
           const int n = m / hw2;
@@ -167,145 +205,136 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
           const int w2 = rem - h2 * p.W2;
           const int ph_ = cls / p.stride, pw_ = cls - ph_ * p.stride;
           if (h2 * p.stride + ph_ < p.H && w2 * p.stride + pw_ < p.W) {
-            a_base[j] = n * p.Ho;
             a_h0[j] = h2 + d_oh;
             a_w0[j] = w2 + d_ow;
+            a_org[j] = ((n * p.Ho + a_h0[j]) * p.Wo + a_w0[j]) * p.lda;
           }
         } else {  // GEMM KC
-          a_base[j] = m;
+          a_org[j] = m * p.lda;
           a_h0[j] = 0;
         }
       }
     }
   }
   const int a_mq = tid % AQPR, a_kr = tid / AQPR;  // MC mapping
-  // B operand
   const int b_mq = tid % BQPR, b_kr = tid / BQPR;
-  int b_r = 0, b_s = 0, b_c = 0;  // WGRAD: fixed filter tap / channel of this thread's column quad
-  bool b_colvalid = true;
+  // B operand, KC (weights / plain rows): element offset of each row, -1 if out of range
+  int b_row[BJ];
+  (void)b_row;
+  if constexpr (!B_MC) {
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int n = n0 + krow8 + 32 * j;
+      b_row[j] = n < p.N ? n * p.ldb : -1;
+    }
+  }
+  // WGRAD B: fixed filter tap / channel of this thread's column quad
+  int w_r = 0, w_s = 0, w_c = 0;
+  bool w_colvalid = true;
   if constexpr (MODE == MODE_WGRAD) {
     const int nn = n0 + b_mq * 4;
-    b_colvalid = nn < p.N;
+    w_colvalid = nn < p.N;
     const int tap = nn / p.C;
-    b_c = nn - tap * p.C;
-    b_r = tap / p.S;
-    b_s = tap - b_r * p.S;
+    w_c = nn - tap * p.C;
+    w_r = tap / p.S;
+    w_s = tap - w_r * p.S;
   }
 
   f32x4 ra[AJ], rb[BJ];
 
-  auto load_tiles = [&](int kt) {
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_begin = split * p.ktps;
+  const int kt_end = (kt_begin + p.ktps > nkt) ? nkt : kt_begin + p.ktps;
+
+  // Issue the (branch-free) global loads of K tile `kt` into ra/rb.  Tiles at or beyond kt_end read as zeros
+  // without touching memory (every lane goes out of range), which lets the main loop run without tail branches.
+  auto load_a = [&](int kt) {
     const int k0 = kt * BK;
-    // ---------------- A ----------------
+    const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!A_MC) {
-      const int kk = k0 + kq * 4;
-      const bool kvalid = kk < p.K;
-      int t_r = 0, t_s = 0, t_c = kk;
+      const unsigned kk = (unsigned)(k0 + kq * 4);
+      const bool kvalid = (int)kk < Klim;
       if constexpr (MODE == MODE_FPROP) {
-        const int tap = kk / p.C;
-        t_c = kk - tap * p.C;
-        t_r = tap / p.S;
-        t_s = tap - t_r * p.S;
-      } else if constexpr (MODE == MODE_DGRAD) {
-        const int tapi = kk / p.Ko;
-        t_c = kk - tapi * p.Ko;
-        t_r = tapi / p.TS;
-        t_s = tapi - t_r * p.TS;
-      }
+        unsigned tap, c, r, s;
+        so_divmod(kk, (unsigned)p.C, invC, tap, c);
+        so_divmod(tap, (unsigned)p.S, invS, r, s);
+        const int tap_off = ((int)r * p.W + (int)s) * p.lda + (int)c;
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == MODE_FPROP) {
-          const int hi = a_h0[j] + t_r, wi = a_w0[j] + t_s;
-          if (kvalid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-            const long long off = ((long long)(a_base[j] + hi) * p.W + wi) * p.lda + t_c;
-            v = *reinterpret_cast<const f32x4*>(gA + off);
-          }
-        } else if constexpr (MODE == MODE_DGRAD) {
-          const int ho = a_h0[j] - t_r, wo = a_w0[j] - t_s;
-          if (kvalid && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo) {
-            const long long off = ((long long)(a_base[j] + ho) * p.Wo + wo) * p.lda + t_c;
-            v = *reinterpret_cast<const f32x4*>(gA + off);
-          }
-        } else {
-          if (kvalid && a_h0[j] == 0) {
-            const long long off = (long long)a_base[j] * p.lda + kk;
-            v = *reinterpret_cast<const f32x4*>(gA + off);
-          }
+        for (int j = 0; j < AJ; ++j) {
+          const int hi = a_h0[j] + (int)r, wi = a_w0[j] + (int)s;
+          const bool ok = kvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
         }
-        ra[j] = v;
+      } else if constexpr (MODE == MODE_DGRAD) {
+        unsigned tapi, ko, tr, ts;
+        so_divmod(kk, (unsigned)p.Ko, invKo, tapi, ko);
+        so_divmod(tapi, (unsigned)p.TS, invTS, tr, ts);
+        const int tap_off = -((int)tr * p.Wo + (int)ts) * p.lda + (int)ko;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+          const int ho = a_h0[j] - (int)tr, wo = a_w0[j] - (int)ts;
+          const bool ok = kvalid & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
+          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+          const bool ok = kvalid & (a_h0[j] == 0);
+          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + (int)kk) * 4u : SO_OOB);
+        }
       }
     } else {
       const int col = m0 + a_mq * 4;
+      const bool colok = col < p.M;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
         const int kk = k0 + a_kr + ARPP * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kk < p.K && col < p.M) {
-          const long long off = (long long)kk * p.lda + col;
-          v = *reinterpret_cast<const f32x4*>(gA + off);
-        }
-        ra[j] = v;
+        const bool ok = colok & (kk < Klim);
+        ra[j] = so_bload(rA, ok ? (unsigned)(kk * p.lda + col) * 4u : SO_OOB);
       }
     }
-    // ---------------- B ----------------
+  };
+  auto load_b = [&](int kt) {
+    const int k0 = kt * BK;
+    const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!B_MC) {
       const int kk = k0 + kq * 4;
-      const bool kvalid = kk < p.K;
+      const bool kvalid = kk < Klim;
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        const int n = n0 + krow8 + 32 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kvalid && n < p.N) {
-          const long long off = (long long)n * p.ldb + kk;
-          v = *reinterpret_cast<const f32x4*>(gB + off);
-        }
-        rb[j] = v;
+        const bool ok = kvalid & (b_row[j] >= 0);
+        rb[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + kk) * 4u : SO_OOB);
       }
     } else {
       const int col = n0 + b_mq * 4;
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const int kk = k0 + b_kr + BRPP * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MODE == MODE_DGRAD) {
-          if (kk < p.K && col < p.N) {
-            const int tapi = kk / p.Ko;
-            const int ko = kk - tapi * p.Ko;
-            const int tr = tapi / p.TS;
-            const int ts = tapi - tr * p.TS;
-            const int r = d_r0 + p.stride * tr, s = d_s0 + p.stride * ts;
-            const long long off = ((long long)ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col;
-            v = *reinterpret_cast<const f32x4*>(gB + off);
-          }
+          unsigned tapi, ko, tr, ts;
+          so_divmod((unsigned)kk, (unsigned)p.Ko, invKo, tapi, ko);
+          so_divmod(tapi, (unsigned)p.TS, invTS, tr, ts);
+          const int r = d_r0 + p.stride * (int)tr, s = d_s0 + p.stride * (int)ts;
+          const bool ok = (kk < Klim) & (col < p.N);
+          rb[j] = so_bload(rB, ok ? (unsigned)(((int)ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
         } else if constexpr (MODE == MODE_WGRAD) {
-          if (kk < p.K && b_colvalid) {
-            const int hw = p.Ho * p.Wo;
-            const int n = kk / hw;
-            const int rem = kk - n * hw;
-            const int ho = rem / p.Wo;
-            const int wo = rem - ho * p.Wo;
-            const int hi = ho * p.stride - p.pad + b_r;
-            const int wi = wo * p.stride - p.pad + b_s;
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-              const long long off = ((long long)(n * p.H + hi) * p.W + wi) * p.ldb + b_c;
-              v = *reinterpret_cast<const f32x4*>(gB + off);
-            }
-          }
+          unsigned n, rem, ho, wo;
+          so_divmod((unsigned)kk, (unsigned)(p.Ho * p.Wo), invHWo, n, rem);
+          so_divmod(rem, (unsigned)p.Wo, invWo, ho, wo);
+          const int hi = (int)ho * p.stride - p.pad + w_r;
+          const int wi = (int)wo * p.stride - p.pad + w_s;
+          const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+          rb[j] = so_bload(rB, ok ? (unsigned)((((int)n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
         } else {
-          if (kk < p.K && col < p.N) {
-            const long long off = (long long)kk * p.ldb + col;
-            v = *reinterpret_cast<const f32x4*>(gB + off);
-          }
+          const bool ok = (kk < Klim) & (col < p.N);
+          rb[j] = so_bload(rB, ok ? (unsigned)(kk * p.ldb + col) * 4u : SO_OOB);
         }
-        rb[j] = v;
       }
     }
   };
 
-  auto store_tiles = [&](int st) {
+  auto store_a = [&](int st) {
     float* as = As + st * A_STAGE;
-    float* bs = Bs + st * B_STAGE;
     if constexpr (!A_MC) {
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
@@ -315,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j)
         *reinterpret_cast<f32x4*>(as + (a_kr + ARPP * j) * BM + a_mq * 4) = ra[j];
     }
+  };
+  auto store_b = [&](int st) {
+    float* bs = Bs + st * B_STAGE;
     if constexpr (!B_MC) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j)
@@ -326,34 +358,28 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
     }
   };
 
-  f32x16 acc[TM][TN];
+  // A wave that owns a single 32x32 output tile would issue every MFMA on the SAME accumulator; an instruction
+  // slotted between two such dependent MFMAs costs a ~43-cycle bubble (MI355X_MICROARCH.md).  Such waves split the
+  // K sum over two accumulators (even / odd k-pairs), added once in the epilogue.
+  // (Measured on MI355X: no gain for v_mfma_f32_32x32x2_f32, whose dependent latency equals its issue time, so
+  //  the split is disabled; kept as a switch.)
+  constexpr int KS = 1;
+  f32x16 acc[TM][TN], acc2[1];  // acc2 is dead code unless KS == 2
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt_begin = split * p.ktps;
-  int kt_end = kt_begin + p.ktps;
-  if (kt_end > nkt) kt_end = nkt;
-
-  if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = (kt + 1) < kt_end;
-    if (more) load_tiles(kt + 1);
-
-    const float* as = As + cur * A_STAGE;
-    const float* bs = Bs + cur * B_STAGE;
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
+  for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
+
+  // multiply K-chunks [kc_lo, kc_hi) (8 k each) of LDS stage `st`
+  auto compute = [&](int st, int kc_lo, int kc_hi) {
+    const float* as = As + st * A_STAGE;
+    const float* bs = Bs + st * B_STAGE;
+#pragma unroll
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
       float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -375,21 +401,63 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
           for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kc * 8 + lh * 4 + t) * BN + wn * WTN + j * 32 + li];
         }
       }
+      if constexpr (KS == 2) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; t += 2) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[0][t], acc[0][0], 0, 0, 0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t + 1], bf[0][t + 1], acc2[0], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+      }
     }
+  };
 
-    if (more) store_tiles(cur ^ 1);
+  // prologue: tile 0 -> LDS[0]; tile 1 in flight in registers
+  load_a(kt_begin);
+  load_b(kt_begin);
+  store_a(0);
+  store_b(0);
+  load_a(kt_begin + 1);
+  load_b(kt_begin + 1);
+  __syncthreads();
+
+  // main loop: one straight-line block per K tile (past-the-end tiles load zeros for free, see load_a).
+  // The four K-chunks of the tile are separated by the staging work for the following tiles so that each
+  // short burst of ds_write / buffer_load issues in the shadow of a 64-cycle MFMA; sched_barrier(0x6) pins the
+  // memory ops and MFMAs in this order while letting the address arithmetic (VALU/SALU) float between MFMAs.
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    compute(cur, 0, 1);
+    __builtin_amdgcn_sched_barrier(0x106);
+    store_a(cur ^ 1);   // tile kt+1, loaded during the previous iteration
+    __builtin_amdgcn_sched_barrier(0x106);
+    compute(cur, 1, 2);
+    __builtin_amdgcn_sched_barrier(0x106);
+    store_b(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0x106);
+    compute(cur, 2, 3);
+    __builtin_amdgcn_sched_barrier(0x106);
+    load_a(kt + 2);     // lands while tile kt+1 is multiplied
+    __builtin_amdgcn_sched_barrier(0x106);
+    compute(cur, 3, 4);
+    __builtin_amdgcn_sched_barrier(0x106);
+    load_b(kt + 2);
     __syncthreads();
     cur ^= 1;
   }
 
   // ---------------- epilogue ----------------
+  if constexpr (KS == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[0][r];
+  }
   const bool to_ws = p.splitk > 1;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -447,15 +515,10 @@ struct SoPlan {
   int bm, bn, splitk, ktps;
 };
 
-// Tile shapes compiled for every mode.  Per-FLOP cost factors relative to 128x128 come from the
-// igemm micro-benchmark (tools/igemm_bench.py); the model is: blocks are dealt round-robin to 256 CUs, a CU's
-// time is (#blocks it owns) x (K tiles per block + prologue/epilogue) x (tile FLOPs / per-CU MFMA rate).
+// Cost model: blocks are dealt round-robin to 256 CUs; a CU's time is (#blocks it owns) x (K tiles per block +
+// prologue/epilogue) x (tile FLOPs / per-CU MFMA rate) x a per-shape factor calibrated with tools/igemm_bench.py.
 static const int kTiles[4][2] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
-// Measured (profiles/r01_igemm_microbench.csv): at the hot path's 1-15 GFLOP layer sizes the 64x64 tile is the
-// most robust (4 blocks/CU hide the per-K-tile staging bubble); the wider tiles only win when they remove a
-// quantisation step, so they carry a penalty.
 static double g_tile_cost[4] = {1.0, 1.12, 1.15, 1.2};
-
 static int g_force_bm = 0, g_force_bn = 0, g_force_splitk = 0;
 
 static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
@@ -488,7 +551,6 @@ static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
 
 // ---- optional live timing of every MFMA launch with HIP events (bench.py's roofline figure) --------
 // Events are recorded on the launch stream around the main kernel only (not the split-K reduce).
-#include <vector>
 struct SoProfRec {
   hipEvent_t e0, e1;
   int key;  // MODE * 4 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128)
@@ -563,6 +625,12 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
 
 static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// extent in bytes of a [rows][ld] fp32 operand; 0 -> too large for the 31-bit offsets used by the loaders
+static unsigned so_extent(long long rows, long long ld) {
+  const long long b = rows * ld * 4;
+  return (b > 0 && b < 0x7FFFFFF0LL) ? (unsigned)b : 0u;
+}
+
 extern "C" {
 
 void so_igemm_force(int bm, int bn, int splitk) {
@@ -610,6 +678,9 @@ int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, 
   p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.M = Nb * p.Ho * p.Wo; p.N = Ko; p.K = R * S * C;
   p.lda = ldx; p.ldb = p.K; p.ldc = ldy; p.ldres = 0;
+  p.a_bytes = so_extent((long long)Nb * H * W, ldx);
+  p.b_bytes = so_extent(Ko, p.K);
+  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = act; p.act_param = act_param; p.nclass = 1;
   return so_launch<MODE_FPROP, false, false>(p, ws_bytes, (hipStream_t)stream);
 }
@@ -629,6 +700,9 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
   p.nclass = stride * stride;
   p.M = Nb * p.H2 * p.W2; p.N = C; p.K = (R / stride) * (S / stride) * Ko;
   p.lda = lddy; p.ldb = C; p.ldc = lddx; p.ldres = 0;
+  p.a_bytes = so_extent((long long)Nb * p.Ho * p.Wo, lddy);
+  p.b_bytes = so_extent((long long)Ko * R * S, C);
+  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = SO_ACT_NONE;
   return so_launch<MODE_DGRAD, false, true>(p, ws_bytes, (hipStream_t)stream);
 }
@@ -646,6 +720,30 @@ int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* d
   p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
   p.M = Ko; p.N = R * S * C; p.K = Nb * p.Ho * p.Wo;
   p.lda = lddy; p.ldb = ldx; p.ldc = p.N; p.ldres = 0;
+  p.a_bytes = so_extent(p.K, lddy);
+  p.b_bytes = so_extent((long long)Nb * H * W, ldx);
+  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24)) return SO_ERR_SHAPE;
+  p.act = SO_ACT_NONE; p.nclass = 1;
+  return so_launch<MODE_WGRAD, true, true>(p, ws_bytes, (hipStream_t)stream);
+}
+
+// Same as so_conv2d_wgrad but dw += (accumulate into an existing gradient slab).
+int so_conv2d_wgrad_acc(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,
+                        int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                        long long ws_bytes, void* stream) {
+  if ((Ko & 3) || (lddy & 3) || (C & 3) || (ldx & 3) || !so_aligned16(dy) || !so_aligned16(x))
+    return SO_ERR_ALIGN;
+  SoIgemm p = {};
+  p.a = dy; p.b = x; p.c = dw; p.ws = ws; p.res = dw;
+  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.M = Ko; p.N = R * S * C; p.K = Nb * p.Ho * p.Wo;
+  p.lda = lddy; p.ldb = ldx; p.ldc = p.N; p.ldres = p.N;
+  p.a_bytes = so_extent(p.K, lddy);
+  p.b_bytes = so_extent((long long)Nb * H * W, ldx);
+  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = SO_ACT_NONE; p.nclass = 1;
   return so_launch<MODE_WGRAD, true, true>(p, ws_bytes, (hipStream_t)stream);
 }
@@ -667,6 +765,9 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
   p.sa = sa; p.sb = sb; p.sc = sc; p.sres = sres;
   p.act = act; p.act_param = act_param; p.nclass = batch;
   p.stride = 1;
+  p.a_bytes = so_extent(transa ? K : M, lda);
+  p.b_bytes = so_extent(transb ? N : K, ldb);
+  if (!p.a_bytes || !p.b_bytes || K >= (1 << 24)) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (!transa && transb) return so_launch<MODE_GEMM, false, false>(p, ws_bytes, st);
   if (!transa && !transb) return so_launch<MODE_GEMM, false, true>(p, ws_bytes, st);

@@ -14,7 +14,25 @@ class VGGLoss(nn.Module):
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
         self.layids = layids
 
+    def _fused_plan(self):
+        """(cfg, params) for ops.vgg_perceptual_loss: the VGG stack flattened in execution order with the tap
+        weight attached to the conv whose ReLU output is compared (relu1_1, 2_1, 3_1, 4_1, 5_1)."""
+        cfg, params = [], []
+        for k, sl in enumerate((self.vgg.slice1, self.vgg.slice2, self.vgg.slice3, self.vgg.slice4, self.vgg.slice5)):
+            convs = [m for m in sl if hasattr(m, "weight")]
+            for m in sl:
+                if hasattr(m, "weight"):
+                    is_tap = m is convs[-1] and (self.layids is None or k in self.layids)
+                    cfg.append(("C", self.weights[k] if is_tap else None))
+                    params += [m.weight, m.bias]
+                elif m.__class__.__name__ == "HipMaxPool2x2":
+                    cfg.append(("M",))
+        return tuple(cfg), params
+
     def forward(self, x, y):
+        if x.is_cuda and x.shape[1] == 3 and not any(p.requires_grad for p in self.vgg.parameters()):
+            cfg, params = self._fused_plan()
+            return ops.vgg_perceptual_loss(x, y, cfg, params)
         x_vgg = self.vgg(x)
         with torch.no_grad():
             y_vgg = self.vgg(y.detach())

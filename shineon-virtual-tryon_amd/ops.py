@@ -168,6 +168,17 @@ def _colsum(t2d_ptr, ld, rows, c, device):
     return out
 
 
+def _direct_grad_ok(p, ohwi):
+    """True if `p` is a parameter whose .grad was planted by HipAdam as a dense view of the flat gradient
+    slab (same memory order as the kernels produce), so kernels may accumulate into it directly."""
+    if not getattr(p, "_so_grad_direct", False) or p.grad is None or not p.requires_grad:
+        return False
+    g = p.grad
+    if g.dtype != torch.float32 or g.data_ptr() % 16:
+        return False
+    return g.permute(0, 2, 3, 1).is_contiguous() if ohwi else g.is_contiguous()
+
+
 # ------------------------------------------------------------------------------------------------
 # Conv2d
 # ------------------------------------------------------------------------------------------------
@@ -194,6 +205,9 @@ class _Conv2dFn(torch.autograd.Function):
         )
         ctx.save_for_backward(xr, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, i, cp, bias is not None, tuple(weight.shape))
+        # parameters whose .grad is a view of the optimizer's flat slab get their gradient accumulated in place
+        ctx.direct = (weight if _direct_grad_ok(weight, ohwi=True) else None,
+                      bias if bias is not None and _direct_grad_ok(bias, ohwi=False) else None)
         return y
 
     @staticmethod
@@ -220,20 +234,37 @@ class _Conv2dFn(torch.autograd.Function):
                 "conv2d_dgrad",
             )
             dx = dxp if cp == i else dxp[:, :i]
+        w_direct, b_direct = ctx.direct
         if ctx.needs_input_grad[1]:
-            dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
-            check(
-                L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
-                                  stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                "conv2d_wgrad",
-            )
-            if cp != i:
-                dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
-                check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
-                dwp = dwd
-            dw = dwp.permute(0, 3, 1, 2)
+            if w_direct is not None and cp == i:
+                # dW += ... straight into the flat gradient slab (split-K reduce / epilogue adds the old value)
+                check(
+                    L.so_conv2d_wgrad_acc(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), w_direct.grad.data_ptr(), n, h, wd,
+                                          cp, o, r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                    "conv2d_wgrad_acc",
+                )
+            else:
+                dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
+                check(
+                    L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
+                                      stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                    "conv2d_wgrad",
+                )
+                if w_direct is not None:  # channel-padded first layer: un-pad while accumulating into the slab
+                    check(L.so_copy2d(dwp.data_ptr(), cp, i, w_direct.grad.data_ptr(), i, i, o * r * s, 1, _stream()), "copy2d")
+                else:
+                    if cp != i:
+                        dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
+                        check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
+                        dwp = dwd
+                    dw = dwp.permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
+            if b_direct is not None:
+                need = L.so_colsum_ws_floats(rows_out, o) * 4
+                wsb = workspace(dev, need)
+                check(L.so_colsum(dy.data_ptr(), _ld(dy), rows_out, o, b_direct.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
+            else:
+                db = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
         return dx, dw, db, None, None, None
 
 
@@ -930,3 +961,97 @@ class _SumFn(torch.autograd.Function):
 
 def tensor_sum(x):
     return _SumFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# VGG19 perceptual loss as ONE autograd node (models/networks/loss.py:106-122 + vgg.py:6-36)
+# ------------------------------------------------------------------------------------------------
+class _VggLossFn(torch.autograd.Function):
+    """sum_i w_i * mean|f_i(x) - f_i(y)| over the five relu taps, VGG weights frozen.
+
+    The prediction x and the target y run through the stack as ONE batch (2B images: deeper layers get a
+    taller GEMM), Conv3x3+ReLU is a single MFMA kernel, and the backward pass walks the x half only:
+    L1 sign gradient injected at each tap, ReLU mask from the saved activations, dgrad (no wgrad: frozen).
+    `cfg` is a tuple of ("C", tap_weight or None) / ("M",) items; `params` = (w0, b0, w1, b1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, y, cfg, *params):
+        L = lib()
+        xr, yr = to_rows(x), to_rows(y.detach())
+        b, c, h, w = xr.shape
+        dev = xr.device
+        cp = (c + 3) // 4 * 4
+        inp = nhwc_empty(2 * b, h, w, cp, dev)
+        half = b * h * w * cp * 4
+        check(L.so_copy2d(xr.data_ptr(), _ld(xr), c, inp.data_ptr(), cp, cp, b * h * w, 0, _stream()), "copy2d")
+        check(L.so_copy2d(yr.data_ptr(), _ld(yr), c, inp.data_ptr() + half, cp, cp, b * h * w, 0, _stream()), "copy2d")
+        ws = workspace(dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        fill_(loss, 0.0)
+        cur, saved, meta, pi = inp, [], [], 0
+        for item in cfg:
+            n2, ci, hh, ww = cur.shape
+            if item[0] == "M":
+                out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
+                check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
+                saved.append(cur)
+                meta.append(("M", len(saved) - 1))
+            else:
+                weight, bias = params[pi], params[pi + 1]
+                pi += 2
+                co = weight.shape[0]
+                wk = _ohwi(weight, cpad=ci)
+                out = nhwc_empty(n2, hh, ww, co, dev)
+                check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
+                                        3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
+                tap_w = item[1]
+                if tap_w is not None:
+                    rows = b * hh * ww
+                    check(L.so_l1_loss_fwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, rows, co, tap_w / (rows * co),
+                                           loss.data_ptr(), 1, ws.data_ptr(), _stream()), "l1_fwd")
+                saved.extend([out, wk])
+                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci))
+            cur = out
+        ctx.save_for_backward(*saved)
+        ctx.meta = (meta, b, c, cp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        L = lib()
+        saved = ctx.saved_tensors
+        meta, b, c, cp = ctx.meta
+        dev = gout.device
+        gout = gout.contiguous()
+        ws = workspace(dev)
+        g = None
+        for m in reversed(meta):
+            if m[0] == "M":
+                xin = saved[m[1]]
+                _, ci, hh, ww = xin.shape
+                dx = nhwc_empty(b, hh, ww, ci, dev)
+                check(L.so_maxpool2_bwd(xin.data_ptr(), ci, g.data_ptr(), ci, dx.data_ptr(), ci, b, hh, ww, ci, _stream()), "maxpool2_bwd")
+                g = dx
+                continue
+            _, oi, wi, tap_w, ci = m
+            out, wk = saved[oi], saved[wi]
+            _, co, hh, ww = out.shape
+            rows = b * hh * ww
+            if tap_w is not None:
+                acc = 1
+                if g is None:
+                    g, acc = nhwc_empty(b, hh, ww, co, dev), 0
+                check(L.so_l1_loss_bwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, gout.data_ptr(), tap_w / (rows * co),
+                                       g.data_ptr(), co, rows, co, acc, _stream()), "l1_bwd")
+            # ReLU mask from the saved activation (in place), then the input gradient
+            check(L.so_act_bwd(out.data_ptr(), co, g.data_ptr(), co, g.data_ptr(), co, rows, co, ACT_RELU, 0.0, _stream()), "act_bwd")
+            dx = nhwc_empty(b, hh, ww, ci, dev)
+            check(L.so_conv2d_dgrad(g.data_ptr(), co, wk.data_ptr(), dx.data_ptr(), ci, b, hh, ww, ci, co, 3, 3, 1, 1,
+                                    ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad")
+            g = dx
+        dxr = g if cp == c else g[:, :c]
+        return (dxr, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def vgg_perceptual_loss(x, y, cfg, params):
+    return _VggLossFn.apply(x, y, cfg, *params)

@@ -46,6 +46,7 @@ class HipAdam(torch.optim.Optimizer):
             p.data = view
             gview = torch.as_strided(flat_g, p.shape, view.stride(), off)
             p.grad = gview
+            p._so_grad_direct = True  # ops.py may accumulate wgrad / bias-grad kernels straight into this view
             off += sz
         self._flat = (flat_p, flat_g, ops.fill_(torch.empty_like(flat_p), 0.0), ops.fill_(torch.empty_like(flat_p), 0.0))
 

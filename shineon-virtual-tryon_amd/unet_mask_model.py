@@ -105,10 +105,14 @@ class UnetMaskModel(BaseModel):
         cloth_inputs = get_and_cat_inputs(batch, hp.cloth_inputs)
 
         p_rendereds, tryon_masks, p_tryons, flow_masks = self.forward(person_inputs, cloth_inputs, flow, prev_im)
-        self.p_tryons = torch.chunk(p_tryons, n, dim=1)
-        self.p_rendereds = torch.chunk(p_rendereds, n, dim=1)
-        self.tryon_masks = torch.chunk(tryon_masks, n, dim=1)
-        self.flow_masks = torch.chunk(flow_masks, n, dim=1) if flow_masks is not None else None
+        pt = torch.chunk(p_tryons, n, dim=1)
+        tm = torch.chunk(tryon_masks, n, dim=1)
+        fm = torch.chunk(flow_masks, n, dim=1) if flow_masks is not None else None
+        # stashed for visualisation only: detached, so the model never pins an autograd graph
+        self.p_tryons = tuple(t.detach() for t in pt)
+        self.p_rendereds = tuple(t.detach() for t in torch.chunk(p_rendereds, n, dim=1))
+        self.tryon_masks = tuple(t.detach() for t in tm)
+        self.flow_masks = tuple(t.detach() for t in fm) if fm is not None else None
         im = torch.chunk(im, n, dim=1)
         cm = torch.chunk(cm, n, dim=1)
 
@@ -120,11 +124,11 @@ class UnetMaskModel(BaseModel):
                 return 0.5 * (curr + prev), curr, prev
             return curr, curr, torch.zeros_like(curr)
 
-        loss_image_l1, l1_curr, l1_prev = both(lambda i: ops.l1_loss(self.p_tryons[i], im[i]))
-        loss_image_vgg, vgg_curr, vgg_prev = both(lambda i: self.criterionVGG(self.p_tryons[i], im[i]))
-        loss_tryon_mask_l1, m_curr, m_prev = both(lambda i: ops.l1_loss(self.tryon_masks[i], cm[i]))
-        if self.flow_masks is not None:
-            loss_flow_mask_l1 = ops.tensor_sum(self.flow_masks[-1]) * hp.pen_flow_mask
+        loss_image_l1, l1_curr, l1_prev = both(lambda i: ops.l1_loss(pt[i], im[i]))
+        loss_image_vgg, vgg_curr, vgg_prev = both(lambda i: self.criterionVGG(pt[i], im[i]))
+        loss_tryon_mask_l1, m_curr, m_prev = both(lambda i: ops.l1_loss(tm[i], cm[i]))
+        if fm is not None:
+            loss_flow_mask_l1 = ops.tensor_sum(fm[-1]) * hp.pen_flow_mask
         else:
             loss_flow_mask_l1 = torch.zeros_like(m_curr) * hp.pen_flow_mask
 

@@ -57,10 +57,12 @@ class WarpModel(BaseModel):
         cloth_inputs = get_and_cat_inputs(batch, self.hparams.cloth_inputs)
 
         grid, theta = self.forward(person_inputs, cloth_inputs)
-        self.warped_cloth = ops.grid_sample(c, grid, padding_mode="border")
+        warped_cloth = ops.grid_sample(c, grid, padding_mode="border")
+        # stashed for visualisation / the next stage only: detached, so the model never pins an autograd graph
+        self.warped_cloth = warped_cloth.detach()
         if "grid_vis" in batch:  # visual only, no loss (warp_model.py:86)
             self.warped_grid = ops.grid_sample(batch["grid_vis"], grid.detach(), padding_mode="zeros")
-        loss = ops.l1_loss(self.warped_cloth, im_c)
+        loss = ops.l1_loss(warped_cloth, im_c)
 
         if not val and self.global_step % self.hparams.display_count == 0:
             self.visualize(batch)

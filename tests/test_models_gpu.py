@@ -70,7 +70,8 @@ def test_unet_mask_model_vs_reference_golden(cuda, variant):
         assert abs(float(res.logs[k]) - ref) <= 2e-5 + 2e-5 * abs(ref), (k, float(res.logs[k]), ref)
     params = dict(model.named_parameters())
     for k in [k for k in g.files if k.startswith("gcs:")]:
-        assert_checksums(params[k[4:]].grad, g[k], rel=1e-2, what=f"{variant} {k}")
+        # floor: the attention gamma gradient is a heavily cancelling sum (|g| ~ 2e-4 from terms ~1e-2)
+        assert_checksums(params[k[4:]].grad, g[k], rel=1e-2, what=f"{variant} {k}", floor=4e-5)
 
 
 def test_unet_mask_full_tensor_vs_oracle(cuda):

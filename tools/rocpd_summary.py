@@ -1,0 +1,57 @@
+"""Summarise a rocprofv3 rocpd (.db) result: per-kernel duration stats and, if present, PMC counter sums.
+
+    python tools/rocpd_summary.py results.db out_prefix      -> out_prefix_kernel_stats.csv, out_prefix_pmc.csv
+"""
+import csv
+import sqlite3
+import sys
+
+
+def main(db, prefix):
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    rows = cur.execute(
+        """select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start)
+           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+           group by s.kernel_name order by 3 desc""").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 3), r[4], r[5]])
+    print(f"{len(rows)} kernels, {tot / 1e6:.3f} ms total kernel time")
+    try:
+        cols = [r[1] for r in cur.execute("pragma table_info(rocpd_pmc_event)")]
+        pcols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_pmc)")]
+        n = cur.execute("select count(*) from rocpd_pmc_event").fetchone()[0]
+    except sqlite3.Error:
+        n = 0
+    if not n:
+        return
+    # pmc_event(event_id -> dispatch event), info_pmc(name); dispatch has event_id
+    q = """select s.kernel_name, p.name, sum(e.value), count(*)
+           from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+           join rocpd_kernel_dispatch d on d.event_id = e.event_id
+           join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+           group by s.kernel_name, p.name"""
+    try:
+        pm = cur.execute(q).fetchall()
+    except sqlite3.Error as ex:
+        print("pmc join failed:", ex, cols, pcols)
+        return
+    names = sorted({r[1] for r in pm})
+    by = {}
+    for k, c, v, cnt in pm:
+        by.setdefault(k, {})[c] = v
+    dur = {r[0]: (r[1], r[2]) for r in rows}
+    with open(prefix + "_pmc.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs"] + names)
+        for k in sorted(by, key=lambda k: -dur.get(k, (0, 0))[1]):
+            w.writerow([k, dur.get(k, (0, 0))[0], dur.get(k, (0, 0))[1]] + [by[k].get(c, "") for c in names])
+    print("pmc counters:", names)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
