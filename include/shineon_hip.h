@@ -47,6 +47,14 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                     long long ws_bytes, void* stream);
 
+/* the same input gradient computed from TRANSPOSED weights wt[c][r][s][ko] (made by so_ohwi_to_ihwo): both
+ * GEMM operands are then k-contiguous, like the forward pass.  C need not be a multiple of 4 here. */
+int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int lddx, int Nb, int H,
+                      int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                      long long ws_bytes, void* stream);
+/* w[ko][tap][c] (OHWI) -> wt[c][tap][ko] (IHWO) */
+int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* stream);
+
 /* weight gradient: dw[ko][r][s][c] (OHWI, dense). */
 int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
@@ -70,6 +78,12 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
  * (0 = auto); set the per-FLOP cost factors of the four tile shapes used by the tile planner. */
 void so_igemm_force(int bm, int bn, int splitk);
 void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x128);
+
+/* measured plans: when enabled, the first launch of every new problem shape (outside stream capture) times all
+ * (tile, split-K) candidates with HIP events on the real operands and caches the fastest; later launches of the
+ * shape (including captured ones) use the cached plan.  so_igemm_plan_count = number of cached shapes. */
+void so_igemm_autotune(int on);
+int so_igemm_plan_count(void);
 
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
  * stream.  so_prof_collect waits for them and fills HOST arrays of 16 entries, key = mode*4 + tile

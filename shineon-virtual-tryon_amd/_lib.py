@@ -70,6 +70,8 @@ def lib():
             fn = getattr(cdll, name)  # AttributeError if the header declares something not exported
             fn.restype = restype
             fn.argtypes = argtypes
+        # measured (tile, split-K) plans per layer shape; SHINEON_AUTOTUNE=0 falls back to the cost model
+        cdll.so_igemm_autotune(0 if os.environ.get("SHINEON_AUTOTUNE", "1") == "0" else 1)
         _lib = cdll
         return _lib
 

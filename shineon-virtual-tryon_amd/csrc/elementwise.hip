@@ -151,6 +151,25 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_k(const float* __restrict__ 
   }
 }
 
+// OHWI weights w[ko][t][c] -> IHWO wt[c][t][ko] (t = filter tap): one LDS tile transpose per (tap, 32x32 tile).
+// The transposed copy lets the input-gradient GEMM read both operands k-contiguous.
+__global__ __launch_bounds__(256) void ohwi_to_ihwo_k(const float* __restrict__ w, float* __restrict__ wt,
+                                                      int Ko, int T, int C) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int ko = k0 + i, c = c0 + tx;
+    tile[i][tx] = (ko < Ko && c < C) ? w[((size_t)ko * T + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, ko = k0 + tx;
+    if (c < C && ko < Ko) wt[((size_t)c * T + t) * Ko + ko] = tile[tx][i];
+  }
+}
+
 // ------------------------------------------------------------------ bilinear x2 upsample
 // PyTorch upsample_bilinear2d, align_corners=False, scale 2:
 //   src = max(0, (o + 0.5) * 0.5 - 0.5); i0 = floor(src); i1 = min(i0 + 1, in - 1); l1 = src - i0.
@@ -583,6 +602,13 @@ int so_nhwc_to_nchw(const float* src, int lds_, float* dst, int Nb, int C, int H
   if (Nb * C * HW <= 0) return 0;
   dim3 grid(so_cdiv(HW, 32), so_cdiv(C, 32), Nb);
   hipLaunchKernelGGL(nhwc_to_nchw_k, grid, dim3(256), 0, (hipStream_t)stream, src, lds_, dst, C, HW);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* stream) {
+  if (Ko <= 0 || taps <= 0 || C <= 0) return 0;
+  dim3 grid(so_cdiv(C, 32), so_cdiv(Ko, 32), taps);
+  hipLaunchKernelGGL(ohwi_to_ihwo_k, grid, dim3(256), 0, (hipStream_t)stream, w, wt, Ko, taps, C);
   return SO_LAUNCH_CHECK();
 }
 

@@ -31,6 +31,8 @@
 //   * fused epilogue: alpha (device scalar, attention gamma) * acc + bias[n] + residual, then activation.
 #include "common.h"
 #include "../../include/shineon_hip.h"
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 enum { MODE_FPROP = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_GEMM = 3 };
@@ -300,10 +302,18 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
     if constexpr (!B_MC) {
       const int kk = k0 + kq * 4;
       const bool kvalid = kk < Klim;
+      int koff = kk;
+      if constexpr (MODE == MODE_DGRAD) {
+        // transposed weights wt[c][r][s][ko]: k index (class tap, ko) -> ((r0 + st*tr) * S + s0 + st*ts) * Ko + ko
+        unsigned tapi, ko, tr, ts;
+        so_divmod((unsigned)kk, (unsigned)p.Ko, invKo, tapi, ko);
+        so_divmod(tapi, (unsigned)p.TS, invTS, tr, ts);
+        koff = ((d_r0 + p.stride * (int)tr) * p.S + d_s0 + p.stride * (int)ts) * p.Ko + (int)ko;
+      }
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const bool ok = kvalid & (b_row[j] >= 0);
-        rb[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + kk) * 4u : SO_OOB);
+        rb[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + koff) * 4u : SO_OOB);
       }
     } else {
       const int col = n0 + b_mq * 4;
@@ -555,7 +565,9 @@ struct SoProfRec {
   hipEvent_t e0, e1;
   int key;  // MODE * 4 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128)
   double flops;
+  int M, N, K, nclass, splitk;
 };
+static const char* g_prof_dump_path = nullptr;
 static bool g_prof_on = false;
 static std::vector<SoProfRec> g_prof;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -592,6 +604,7 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
     rec.e1 = so_prof_event();
     rec.key = MODE * 4 + (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0);
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
@@ -612,15 +625,87 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
 }
 
 template <int MODE, bool A_MC, bool B_MC>
-static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
-  if (p.M <= 0 || p.N <= 0) return 0;
-  const SoPlan plan = so_plan(p, p.ws ? ws_bytes / 4 : 0);
+static int so_launch_plan(SoIgemm& p, const SoPlan& plan, hipStream_t stream) {
   p.splitk = plan.splitk;
   p.ktps = plan.ktps;
   if (plan.bm == 128 && plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 128>(p, stream);
   if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 64>(p, stream);
   if (plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 64, 128>(p, stream);
   return so_launch_tile<MODE, A_MC, B_MC, 64, 64>(p, stream);
+}
+
+// ---- measured plans -------------------------------------------------------------------------------------
+// The layer shapes of a training run repeat every step, so the first time a problem shape is seen (outside a
+// stream capture) every (tile, split-K) candidate is timed once with HIP events on the real operands and the
+// fastest is cached; afterwards the lookup is a map access.  Tuning launches write to scratch behind the split-K
+// slabs, never to the caller's output (which may be an accumulating gradient slab).
+#include <map>
+#include <array>
+static int g_autotune = 0;
+static std::map<std::array<int, 12>, SoPlan> g_plan_cache;
+
+template <int MODE, bool A_MC, bool B_MC>
+static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return 0;
+  const long long ws_floats = p.ws ? ws_bytes / 4 : 0;
+  if (g_force_bm || g_force_splitk || !g_autotune) return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);
+  const std::array<int, 12> key = {MODE, (int)A_MC * 2 + (int)B_MC, p.M, p.N, p.K, p.nclass, p.R, p.S, p.stride, p.C, p.Ko,
+                                   p.lda * 31 + p.ldb};
+  auto it = g_plan_cache.find(key);
+  if (it != g_plan_cache.end()) return so_launch_plan<MODE, A_MC, B_MC>(p, it->second, stream);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cap);
+  const long long mn = (long long)p.nclass * p.M * p.N;
+  if (cap != hipStreamCaptureStatusNone || ws_floats < 2 * mn)
+    return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);
+
+  const int nkt = so_cdiv(p.K, 32);
+  SoPlan best = so_plan(p, ws_floats);
+  float best_ms = 1e30f;
+  const bool was_prof = g_prof_on;
+  g_prof_on = false;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  SoIgemm q = p;
+  q.res = nullptr;
+  q.ldres = 0;
+  int err = 0;
+  for (int ti = 0; ti < 4 && !err; ++ti) {
+    int last_ktps = -1;
+    for (int sk = 1; sk <= 256 && !err; sk *= 2) {
+      if (sk > nkt) break;
+      const int ktps = so_cdiv(nkt, sk);
+      const int sk_eff = so_cdiv(nkt, ktps);
+      if (ktps == last_ktps) continue;                          // same plan as the previous power of two
+      last_ktps = ktps;
+      if ((long long)(sk_eff > 1 ? sk_eff : 0) * mn + mn > ws_floats) continue;
+      const long long blocks = (long long)so_cdiv(p.M, kTiles[ti][0]) * so_cdiv(p.N, kTiles[ti][1]) * p.nclass * sk_eff;
+      if (blocks > 65536 || (sk_eff > 1 && blocks > 8192)) continue;
+      SoPlan cand = {kTiles[ti][0], kTiles[ti][1], sk_eff, ktps};
+      q.c = p.ws + (long long)(sk_eff > 1 ? sk_eff : 0) * mn;   // scratch output behind the slabs
+      if constexpr (MODE == MODE_GEMM) q.sc = (long long)p.M * p.N;
+      q.ldc = (MODE == MODE_DGRAD && p.nclass > 1) ? p.ldc : p.N;
+      if (MODE == MODE_DGRAD && p.nclass > 1) q.c = p.c;        // class-scattered rows: idempotent overwrite of dx
+      float ms = 0.f;
+      for (int rep = 0; rep < 2 && !err; ++rep) {
+        (void)hipEventRecord(e0, stream);
+        err = so_launch_plan<MODE, A_MC, B_MC>(q, cand, stream);
+        (void)hipEventRecord(e1, stream);
+        if (!err && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+      }
+      if (!err && ms > 0.f && ms < best_ms) {
+        best_ms = ms;
+        best = cand;
+      }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  g_prof_on = was_prof;
+  if (err) return err;
+  g_plan_cache[key] = best;
+  return so_launch_plan<MODE, A_MC, B_MC>(p, best, stream);
 }
 
 static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -643,6 +728,9 @@ void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x1
   g_tile_cost[0] = c64x64; g_tile_cost[1] = c128x64; g_tile_cost[2] = c64x128; g_tile_cost[3] = c128x128;
 }
 
+void so_igemm_autotune(int on) { g_autotune = on; }
+int so_igemm_plan_count(void) { return (int)g_plan_cache.size(); }
+
 void so_prof_enable(int on) { g_prof_on = on != 0; }
 
 // Waits for every recorded launch, then fills per-key totals (key = mode*4 + tile index, 16 keys):
@@ -651,9 +739,15 @@ void so_prof_enable(int on) { g_prof_on = on != 0; }
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
   for (int k = 0; k < 16; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
   int n = 0;
+  FILE* dump = nullptr;
+  if (const char* path = getenv("SO_PROF_DUMP")) dump = fopen(path, "w");
+  if (dump) fprintf(dump, "key,M,N,K,nclass,splitk,us,tflops\n");
   for (auto& r : g_prof) {
     float ms = 0.f;
     if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      if (dump)
+        fprintf(dump, "%d,%d,%d,%d,%d,%d,%.2f,%.2f\n", r.key, r.M, r.N, r.K, r.nclass, r.splitk, ms * 1e3,
+                ms > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
       out_ms[r.key] += ms;
       out_flops[r.key] += (float)r.flops;
       out_count[r.key] += 1;
@@ -662,6 +756,7 @@ int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
     g_prof_pool.push_back(r.e0);
     g_prof_pool.push_back(r.e1);
   }
+  if (dump) fclose(dump);
   g_prof.clear();
   return n;
 }
@@ -705,6 +800,30 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
   if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = SO_ACT_NONE;
   return so_launch<MODE_DGRAD, false, true>(p, ws_bytes, (hipStream_t)stream);
+}
+
+// Input gradient with TRANSPOSED weights wt[c][r][s][ko] (so_ohwi_to_ihwo): both operands are k-contiguous, the
+// kernel runs in the same KC x KC mode as the forward convolution (ds_read_b128 fragments on both sides).
+int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int lddx, int Nb, int H,
+                      int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                      long long ws_bytes, void* stream) {
+  if ((Ko & 3) || (lddy & 3) || !so_aligned16(dy) || !so_aligned16(wt)) return SO_ERR_ALIGN;
+  if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
+  SoIgemm p = {};
+  p.a = dy; p.b = wt; p.c = dx; p.ws = ws;
+  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
+  p.Ho = (H + 2 * pad - R) / stride + 1;
+  p.Wo = (W + 2 * pad - S) / stride + 1;
+  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.TS = S / stride; p.H2 = (H + stride - 1) / stride; p.W2 = (W + stride - 1) / stride;
+  p.nclass = stride * stride;
+  p.M = Nb * p.H2 * p.W2; p.N = C; p.K = (R / stride) * (S / stride) * Ko;
+  p.lda = lddy; p.ldb = R * S * Ko; p.ldc = lddx; p.ldres = 0;
+  p.a_bytes = so_extent((long long)Nb * p.Ho * p.Wo, lddy);
+  p.b_bytes = so_extent(C, (long long)R * S * Ko);
+  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
+  p.act = SO_ACT_NONE;
+  return so_launch<MODE_DGRAD, false, false>(p, ws_bytes, (hipStream_t)stream);
 }
 
 int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,

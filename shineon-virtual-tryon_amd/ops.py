@@ -8,6 +8,7 @@ and a channel slice of a wider NHWC buffer when ld > C, so the reference's NCHW-
 interfaces are kept while the kernels see "pixel rows x channel columns".
 """
 import math
+import weakref
 
 import torch
 
@@ -159,6 +160,30 @@ def _ohwi(weight, cpad=None):
     return out
 
 
+_IHWO_CACHE = {}
+
+
+def _ihwo(w_ohwi, owner=None):
+    """(O, R, S, C) dense OHWI weights -> (C, R, S, O) transposed copy for the KC x KC input-gradient GEMM.
+    owner (for frozen weights): (weakref to the owning parameter, its _version at forward time); the copy is
+    cached per parameter OBJECT and version, never per address (addresses are recycled between models)."""
+    if owner is not None:
+        ref, version = owner
+        p = ref()
+        hit = _IHWO_CACHE.get(id(p)) if p is not None else None
+        if hit is not None and hit[0]() is p and hit[1] == version and hit[2].shape[0] == w_ohwi.shape[3]:
+            return hit[2]
+    o, r, s, c = w_ohwi.shape
+    wt = torch.empty((c, r, s, o), dtype=torch.float32, device=w_ohwi.device)
+    check(lib().so_ohwi_to_ihwo(w_ohwi.data_ptr(), wt.data_ptr(), o, r * s, c, _stream()), "ohwi_to_ihwo")
+    if owner is not None and owner[0]() is not None:
+        dead = [k for k, v in _IHWO_CACHE.items() if v[0]() is None]
+        for k in dead:
+            del _IHWO_CACHE[k]
+        _IHWO_CACHE[id(owner[0]())] = (owner[0], owner[1], wt)
+    return wt
+
+
 def _colsum(t2d_ptr, ld, rows, c, device):
     L = lib()
     out = torch.empty(c, dtype=torch.float32, device=device)
@@ -228,10 +253,11 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dxp = nhwc_empty(n, h, wd, cp, dev)
+            wt = _ihwo(w)  # transposed weights: both GEMM operands k-contiguous (same mode as the forward conv)
             check(
-                L.so_conv2d_dgrad(dy.data_ptr(), _ld(dy), w.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, o, r, s,
-                                  stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                "conv2d_dgrad",
+                L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, o, r, s,
+                                    stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                "conv2d_dgrad_t",
             )
             dx = dxp if cp == i else dxp[:, :i]
         w_direct, b_direct = ctx.direct
@@ -1010,7 +1036,7 @@ class _VggLossFn(torch.autograd.Function):
                     check(L.so_l1_loss_fwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, rows, co, tap_w / (rows * co),
                                            loss.data_ptr(), 1, ws.data_ptr(), _stream()), "l1_fwd")
                 saved.extend([out, wk])
-                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci))
+                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci, (weakref.ref(weight), weight._version)))
             cur = out
         ctx.save_for_backward(*saved)
         ctx.meta = (meta, b, c, cp)
@@ -1033,7 +1059,7 @@ class _VggLossFn(torch.autograd.Function):
                 check(L.so_maxpool2_bwd(xin.data_ptr(), ci, g.data_ptr(), ci, dx.data_ptr(), ci, b, hh, ww, ci, _stream()), "maxpool2_bwd")
                 g = dx
                 continue
-            _, oi, wi, tap_w, ci = m
+            _, oi, wi, tap_w, ci, wkey = m
             out, wk = saved[oi], saved[wi]
             _, co, hh, ww = out.shape
             rows = b * hh * ww
@@ -1046,8 +1072,9 @@ class _VggLossFn(torch.autograd.Function):
             # ReLU mask from the saved activation (in place), then the input gradient
             check(L.so_act_bwd(out.data_ptr(), co, g.data_ptr(), co, g.data_ptr(), co, rows, co, ACT_RELU, 0.0, _stream()), "act_bwd")
             dx = nhwc_empty(b, hh, ww, ci, dev)
-            check(L.so_conv2d_dgrad(g.data_ptr(), co, wk.data_ptr(), dx.data_ptr(), ci, b, hh, ww, ci, co, 3, 3, 1, 1,
-                                    ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad")
+            wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
+            check(L.so_conv2d_dgrad_t(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, b, hh, ww, ci, co, 3, 3, 1, 1,
+                                      ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_t")
             g = dx
         dxr = g if cp == c else g[:, :c]
         return (dxr, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
