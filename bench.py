@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--plans", default="", help="file with measured igemm plans: loaded if present (skips the "
+                    "one-off tuning sweep, e.g. under a profiler), written back at the end")
     args = ap.parse_args()
 
     rank, world = init_distributed()
@@ -125,6 +127,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     dev = torch.device("cuda", torch.cuda.current_device())
     L = pkg.lib()
+    if args.plans and os.path.exists(args.plans):
+        log(f"loaded {L.so_igemm_plans_load(args.plans.encode())} igemm plans from {args.plans}")
 
     torch.manual_seed(420)
     warp = WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).to(dev).train()
@@ -251,6 +255,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_iters)
         print(json.dumps(out), flush=True)
+    if args.plans and rank == 0:
+        log(f"saved {L.so_igemm_plans_save(args.plans.encode())} igemm plans to {args.plans}")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -84,6 +84,9 @@ void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x1
  * shape (including captured ones) use the cached plan.  so_igemm_plan_count = number of cached shapes. */
 void so_igemm_autotune(int on);
 int so_igemm_plan_count(void);
+/* persist / restore the measured plans (text file); return the number of plans, -1 on I/O error */
+int so_igemm_plans_save(const char* path);
+int so_igemm_plans_load(const char* path);
 
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
  * stream.  so_prof_collect waits for them and fills HOST arrays of 16 entries, key = mode*4 + tile

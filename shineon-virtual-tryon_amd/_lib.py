@@ -21,6 +21,7 @@ _CTYPES = {
     "float*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
+    "const char*": ctypes.c_char_p,
     "int": ctypes.c_int,
     "long long": ctypes.c_longlong,
     "float": ctypes.c_float,
@@ -40,7 +41,7 @@ def prototypes(header_path=HEADER_PATH):
             a = re.sub(r"\s+", " ", a)
             if a == "void":
                 continue
-            mm = re.match(r"(const float\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
+            mm = re.match(r"(const float\*|const char\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
             if not mm:
                 raise RuntimeError(f"cannot parse argument '{a}' of {name}")
             argtypes.append(_CTYPES[mm.group(1)])

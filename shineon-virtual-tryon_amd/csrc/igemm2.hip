@@ -731,6 +731,39 @@ void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x1
 void so_igemm_autotune(int on) { g_autotune = on; }
 int so_igemm_plan_count(void) { return (int)g_plan_cache.size(); }
 
+// Plan cache persistence (one text line per shape: 12 key ints, then bm bn splitk ktps).  Returns the number
+// of plans written / read, or -1 if the file cannot be opened.
+int so_igemm_plans_save(const char* path) {
+  FILE* f = fopen(path, "w");
+  if (!f) return -1;
+  for (const auto& kv : g_plan_cache) {
+    for (int v : kv.first) fprintf(f, "%d ", v);
+    fprintf(f, "%d %d %d %d\n", kv.second.bm, kv.second.bn, kv.second.splitk, kv.second.ktps);
+  }
+  fclose(f);
+  return (int)g_plan_cache.size();
+}
+
+int so_igemm_plans_load(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int n = 0;
+  for (;;) {
+    std::array<int, 12> key;
+    SoPlan pl;
+    bool ok = true;
+    for (int i = 0; i < 12 && ok; ++i) ok = fscanf(f, "%d", &key[i]) == 1;
+    ok = ok && fscanf(f, "%d %d %d %d", &pl.bm, &pl.bn, &pl.splitk, &pl.ktps) == 4;
+    if (!ok) break;
+    if ((pl.bm == 64 || pl.bm == 128) && (pl.bn == 64 || pl.bn == 128) && pl.splitk >= 1 && pl.ktps >= 1) {
+      g_plan_cache[key] = pl;
+      ++n;
+    }
+  }
+  fclose(f);
+  return n;
+}
+
 void so_prof_enable(int on) { g_prof_on = on != 0; }
 
 // Waits for every recorded launch, then fills per-key totals (key = mode*4 + tile index, 16 keys):
