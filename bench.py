@@ -34,7 +34,8 @@ from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel  # noqa: E40
 from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
-KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm") for t in ("64x64", "128x64", "64x128", "128x128")]
+KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
+             for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "-", "-")]
 
 
 def hparams(**kw):
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--serial-wgrad", action="store_true", help="no side stream for weight gradients")
     ap.add_argument("--plans", default="", help="file with measured igemm plans: loaded if present (skips the "
                     "one-off tuning sweep, e.g. under a profiler), written back at the end")
     args = ap.parse_args()
@@ -154,6 +156,17 @@ def main():
         res = unet.training_step(b2, 0)
         res.minimize.backward()
         optu.step(grad_scale=redu.all_reduce())
+
+    # first step: every new layer shape times its (tile, split-K) candidates; keep the streams serial meanwhile so
+    # the measurements are not disturbed by the concurrent weight-gradient stream
+    from shineon_virtual_tryon_amd import ops as so_ops
+
+    concurrent = so_ops.CONCURRENT_WGRAD and not args.serial_wgrad
+    so_ops.CONCURRENT_WGRAD = False
+    eager_step()
+    torch.cuda.synchronize()
+    so_ops.CONCURRENT_WGRAD = concurrent
+    log(f"{L.so_igemm_plan_count()} igemm plans measured; concurrent wgrad stream: {concurrent}")
 
     step = eager_step
     if not args.no_graph:
@@ -212,16 +225,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ms = (ctypes.c_float * 16)()
-    fl = (ctypes.c_float * 16)()
-    cnt = (ctypes.c_int * 16)()
+    ms = (ctypes.c_float * 32)()
+    fl = (ctypes.c_float * 32)()
+    cnt = (ctypes.c_int * 32)()
     L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
 
     if rank == 0:
         kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / prof_steps,
                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
-                   for k in range(16) if cnt[k] > 0}
-        dom = max(range(16), key=lambda k: ms[k])
+                   for k in range(32) if cnt[k] > 0}
+        dom = max(range(32), key=lambda k: ms[k])
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         mfma_ms = sum(ms) / prof_steps
         out = {

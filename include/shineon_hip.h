@@ -77,6 +77,7 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
 /* test / tuning hooks: force the block tile (bm, bn in {64, 128}; bm = 0 -> auto) and the split-K factor
  * (0 = auto); set the per-FLOP cost factors of the four tile shapes used by the tile planner. */
 void so_igemm_force(int bm, int bn, int splitk);
+void so_igemm_force_waves(int nw); /* after so_igemm_force: 8 selects the 8-wave variant of a BN = 128 tile */
 void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x128);
 
 /* measured plans: when enabled, the first launch of every new problem shape (outside stream capture) times all
@@ -89,8 +90,9 @@ int so_igemm_plans_save(const char* path);
 int so_igemm_plans_load(const char* path);
 
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
- * stream.  so_prof_collect waits for them and fills HOST arrays of 16 entries, key = mode*4 + tile
- * (mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm; tile 0 64x64, 1 128x64, 2 64x128, 3 128x128): summed milliseconds, summed algorithmic FLOPs
+ * stream.  so_prof_collect waits for them and fills HOST arrays of 32 entries, key = mode*8 + tile
+ * (mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm; tile 0 64x64, 1 128x64, 2 64x128, 3 128x128, 4 128x128/8 waves,
+ * 5 64x128/8 waves): summed milliseconds, summed algorithmic FLOPs
  * (2*M*N*K per launch), launch count.  Returns the number of launches collected and clears the list. */
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);

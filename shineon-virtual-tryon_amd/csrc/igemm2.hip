@@ -125,17 +125,23 @@ __device__ __forceinline__ f32x4 so_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return r;
 }
 
-template <int MODE, bool A_MC, bool B_MC, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
+// NW = waves per block: 4 (2x2 wave grid) or 8 (2x4, BN = 128 only: twice the waves per SIMD for the same LDS
+// footprint, which hides the staging bubbles of the large tiles).
+template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
+  constexpr int NT = NW * 64;
   constexpr int LDK = 36;  // KC row pitch: 144 B -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots
   constexpr int A_STAGE = A_MC ? BK * BM : BM * LDK;
   constexpr int B_STAGE = B_MC ? BK * BN : BN * LDK;
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int WGN = NW / 2;                          // waves along N
+  constexpr int WTM = BM / 2, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AJ = BM / 32, BJ = BN / 32;            // 16-byte quads staged per thread per K tile
+  static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
+  constexpr int RPP = NT / 8;                          // KC mode: tile rows covered per pass
+  constexpr int AJ = BM / RPP, BJ = BN / RPP;          // 16-byte quads staged per thread per K tile
   constexpr int AQPR = BM / 4, BQPR = BN / 4;          // MC mode: quads per k-row
-  constexpr int ARPP = 256 / AQPR, BRPP = 256 / BQPR;  // MC mode: k-rows covered per pass
+  constexpr int ARPP = NT / AQPR, BRPP = NT / BQPR;    // MC mode: k-rows covered per pass
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tile_m = blockIdx.x / tiles_n;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
   if constexpr (!A_MC) {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int m = m0 + krow8 + 32 * j;
+      const int m = m0 + krow8 + RPP * j;
       a_org[j] = 0; a_h0[j] = -(1 << 28); a_w0[j] = 0;
       if (m < p.M) {
         if constexpr (MODE == MODE_FPROP) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
   if constexpr (!B_MC) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int n = n0 + krow8 + 32 * j;
+      const int n = n0 + krow8 + RPP * j;
       b_row[j] = n < p.N ? n * p.ldb : -1;
     }
   }
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
     if constexpr (!A_MC) {
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
-        *reinterpret_cast<f32x4*>(as + (krow8 + 32 * j) * LDK + kq * 4) = ra[j];
+        *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = ra[j];
     } else {
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void so_igemm_kernel(const SoIgemm p) {
     if constexpr (!B_MC) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j)
-        *reinterpret_cast<f32x4*>(bs + (krow8 + 32 * j) * LDK + kq * 4) = rb[j];
+        *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = rb[j];
     } else {
 #pragma unroll
       for (int j = 0; j < BJ; ++j)
@@ -522,22 +528,24 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
 // Host side: tile / split-K selection and launch.
 // ------------------------------------------------------------------------------------------------
 struct SoPlan {
-  int bm, bn, splitk, ktps;
+  int bm, bn, splitk, ktps, nw;
 };
 
 // Cost model: blocks are dealt round-robin to 256 CUs; a CU's time is (#blocks it owns) x (K tiles per block +
 // prologue/epilogue) x (tile FLOPs / per-CU MFMA rate) x a per-shape factor calibrated with tools/igemm_bench.py.
-static const int kTiles[4][2] = {{64, 64}, {128, 64}, {64, 128}, {128, 128}};
-static double g_tile_cost[4] = {1.0, 1.12, 1.15, 1.2};
-static int g_force_bm = 0, g_force_bn = 0, g_force_splitk = 0;
+// {BM, BN, waves}: tile index 0-3 = 4 waves, 4-5 = 8 waves (BN = 128 only)
+constexpr int kNTiles = 6;
+static const int kTiles[kNTiles][3] = {{64, 64, 4}, {128, 64, 4}, {64, 128, 4}, {128, 128, 4}, {128, 128, 8}, {64, 128, 8}};
+static double g_tile_cost[kNTiles] = {1.0, 1.12, 1.15, 1.2, 1.1, 1.1};
+static int g_force_bm = 0, g_force_bn = 0, g_force_splitk = 0, g_force_nw = 0;
 
 static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
   const int nkt = so_cdiv(p.K, 32);
-  SoPlan best = {64, 64, 1, nkt};
+  SoPlan best = {64, 64, 1, nkt, 4};
   double best_cost = 1e30;
-  for (int ti = 0; ti < 4; ++ti) {
-    const int bm = kTiles[ti][0], bn = kTiles[ti][1];
-    if (g_force_bm && (bm != g_force_bm || bn != g_force_bn)) continue;
+  for (int ti = 0; ti < kNTiles; ++ti) {
+    const int bm = kTiles[ti][0], bn = kTiles[ti][1], nw = kTiles[ti][2];
+    if (g_force_bm && (bm != g_force_bm || bn != g_force_bn || nw != (g_force_nw ? g_force_nw : 4))) continue;
     const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bn) * p.nclass;
     for (int sk = 1; sk <= 512; sk *= 2) {
       if (g_force_splitk && sk != g_force_splitk) continue;
@@ -552,7 +560,7 @@ static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
       if (sk_eff > 1) cost += 3e-6 + (double)(sk_eff + 1) * p.nclass * p.M * p.N * 4.0 / 3e12;
       if (cost < best_cost) {
         best_cost = cost;
-        best = {bm, bn, sk_eff, ktps};
+        best = {bm, bn, sk_eff, ktps, nw};
       }
     }
   }
@@ -583,12 +591,12 @@ static hipEvent_t so_prof_event() {
   return e;
 }
 
-template <int MODE, bool A_MC, bool B_MC, int BM, int BN>
+template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   constexpr int A_STAGE = A_MC ? 32 * BM : BM * 36;
   constexpr int B_STAGE = B_MC ? 32 * BN : BN * 36;
   constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
-  auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN>;
+  auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -602,12 +610,12 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   if (g_prof_on) {
     rec.e0 = so_prof_event();
     rec.e1 = so_prof_event();
-    rec.key = MODE * 4 + (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0);
+    rec.key = MODE * 8 + (NW == 8 ? (BM == 128 ? 4 : 5) : (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0));
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
   if (g_prof_on) {
     (void)hipEventRecord(rec.e1, stream);
     g_prof.push_back(rec);
@@ -628,10 +636,14 @@ template <int MODE, bool A_MC, bool B_MC>
 static int so_launch_plan(SoIgemm& p, const SoPlan& plan, hipStream_t stream) {
   p.splitk = plan.splitk;
   p.ktps = plan.ktps;
-  if (plan.bm == 128 && plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 128>(p, stream);
-  if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 64>(p, stream);
-  if (plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 64, 128>(p, stream);
-  return so_launch_tile<MODE, A_MC, B_MC, 64, 64>(p, stream);
+  if (plan.nw == 8 && plan.bn == 128) {
+    if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 128, 8>(p, stream);
+    return so_launch_tile<MODE, A_MC, B_MC, 64, 128, 8>(p, stream);
+  }
+  if (plan.bm == 128 && plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 128, 4>(p, stream);
+  if (plan.bm == 128) return so_launch_tile<MODE, A_MC, B_MC, 128, 64, 4>(p, stream);
+  if (plan.bn == 128) return so_launch_tile<MODE, A_MC, B_MC, 64, 128, 4>(p, stream);
+  return so_launch_tile<MODE, A_MC, B_MC, 64, 64, 4>(p, stream);
 }
 
 // ---- measured plans -------------------------------------------------------------------------------------
@@ -671,7 +683,7 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   q.res = nullptr;
   q.ldres = 0;
   int err = 0;
-  for (int ti = 0; ti < 4 && !err; ++ti) {
+  for (int ti = 0; ti < kNTiles && !err; ++ti) {
     int last_ktps = -1;
     for (int sk = 1; sk <= 256 && !err; sk *= 2) {
       if (sk > nkt) break;
@@ -682,7 +694,7 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
       if ((long long)(sk_eff > 1 ? sk_eff : 0) * mn + mn > ws_floats) continue;
       const long long blocks = (long long)so_cdiv(p.M, kTiles[ti][0]) * so_cdiv(p.N, kTiles[ti][1]) * p.nclass * sk_eff;
       if (blocks > 65536 || (sk_eff > 1 && blocks > 8192)) continue;
-      SoPlan cand = {kTiles[ti][0], kTiles[ti][1], sk_eff, ktps};
+      SoPlan cand = {kTiles[ti][0], kTiles[ti][1], sk_eff, ktps, kTiles[ti][2]};
       q.c = p.ws + (long long)(sk_eff > 1 ? sk_eff : 0) * mn;   // scratch output behind the slabs
       if constexpr (MODE == MODE_GEMM) q.sc = (long long)p.M * p.N;
       q.ldc = (MODE == MODE_DGRAD && p.nclass > 1) ? p.ldc : p.N;
@@ -722,7 +734,10 @@ void so_igemm_force(int bm, int bn, int splitk) {
   g_force_bm = bm;
   g_force_bn = bn;
   g_force_splitk = splitk;
+  g_force_nw = 0;
 }
+
+void so_igemm_force_waves(int nw) { g_force_nw = nw; }
 
 void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x128) {
   g_tile_cost[0] = c64x64; g_tile_cost[1] = c128x64; g_tile_cost[2] = c64x128; g_tile_cost[3] = c128x128;
@@ -738,7 +753,7 @@ int so_igemm_plans_save(const char* path) {
   if (!f) return -1;
   for (const auto& kv : g_plan_cache) {
     for (int v : kv.first) fprintf(f, "%d ", v);
-    fprintf(f, "%d %d %d %d\n", kv.second.bm, kv.second.bn, kv.second.splitk, kv.second.ktps);
+    fprintf(f, "%d %d %d %d %d\n", kv.second.bm, kv.second.bn, kv.second.splitk, kv.second.ktps, kv.second.nw);
   }
   fclose(f);
   return (int)g_plan_cache.size();
@@ -753,9 +768,10 @@ int so_igemm_plans_load(const char* path) {
     SoPlan pl;
     bool ok = true;
     for (int i = 0; i < 12 && ok; ++i) ok = fscanf(f, "%d", &key[i]) == 1;
-    ok = ok && fscanf(f, "%d %d %d %d", &pl.bm, &pl.bn, &pl.splitk, &pl.ktps) == 4;
+    ok = ok && fscanf(f, "%d %d %d %d %d", &pl.bm, &pl.bn, &pl.splitk, &pl.ktps, &pl.nw) == 5;
     if (!ok) break;
-    if ((pl.bm == 64 || pl.bm == 128) && (pl.bn == 64 || pl.bn == 128) && pl.splitk >= 1 && pl.ktps >= 1) {
+    if ((pl.bm == 64 || pl.bm == 128) && (pl.bn == 64 || pl.bn == 128) && pl.splitk >= 1 && pl.ktps >= 1 &&
+        (pl.nw == 4 || (pl.nw == 8 && pl.bn == 128))) {
       g_plan_cache[key] = pl;
       ++n;
     }
@@ -766,11 +782,11 @@ int so_igemm_plans_load(const char* path) {
 
 void so_prof_enable(int on) { g_prof_on = on != 0; }
 
-// Waits for every recorded launch, then fills per-key totals (key = mode*4 + tile index, 16 keys):
+// Waits for every recorded launch, then fills per-key totals (key = mode*8 + tile index, 32 keys):
 // out_ms[k] = summed kernel time in ms, out_flops[k] = summed algorithmic FLOPs, out_count[k] = launches.
 // Clears the record list.  Returns the number of launches collected.
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
-  for (int k = 0; k < 16; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
+  for (int k = 0; k < 32; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
   int n = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("SO_PROF_DUMP")) dump = fopen(path, "w");

@@ -36,15 +36,50 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def workspace(device, min_bytes=0):
-    """Per-device scratch slab (split-K slabs, reduction partials)."""
-    key = (device.type, device.index)
+def workspace(device, min_bytes=0, lane=0):
+    """Per-device scratch slab (split-K slabs, reduction partials).  `lane` selects an independent slab for work
+    issued on the side stream (weight gradients running concurrently with input gradients)."""
+    key = (device.type, device.index, lane)
     ws = _WS.get(key)
     need = max(_WS_BYTES, int(min_bytes))
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws
+
+
+_SIDE = {}
+# Weight/bias gradients on a side stream, overlapping the input-gradient GEMM.  Measured on MI355X (bench.py
+# --steps 10): 289 frames/s with, 293 without — both GEMMs already fill the CUs, so sharing them only stretches
+# each kernel.  Off by default; kept as an experiment switch.
+CONCURRENT_WGRAD = False
+
+
+class _SideStream:
+    """Fork/join helper: `with side(device) as st:` runs the body on a second HIP stream that first waits for
+    the current stream and is joined back by `join()`.  Works eagerly and inside a stream capture (the fork and
+    join become graph edges).  Tensors used in the body must stay alive until join() has been called."""
+
+    def __init__(self, device):
+        self.cur = torch.cuda.current_stream(device)
+        key = (device.index, self.cur.cuda_stream)
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device)
+        self.side = _SIDE[key]
+        self.ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self.side
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        self.cur.wait_stream(self.side)
 
 
 def nhwc_empty(n, h, w, c, device, ld=None):
@@ -249,9 +284,56 @@ class _Conv2dFn(torch.autograd.Function):
             g = nhwc_empty(dy.shape[0], dy.shape[2], dy.shape[3], o, dev)
             check(L.so_act_bwd(y.data_ptr(), _ld(y), dy.data_ptr(), _ld(dy), g.data_ptr(), o, rows_out, o, act, 0.0, _stream()), "act_bwd")
             dy = g
-        ws = workspace(dev)
         dx = dw = db = None
+        w_direct, b_direct = ctx.direct
+        need_w = ctx.needs_input_grad[1]
+        need_b = has_bias and ctx.needs_input_grad[2]
+
+        def weight_grads(lane):
+            """dW (+ d bias) on the current stream with the scratch slab of `lane`."""
+            dw_, db_ = None, None
+            wsl = workspace(dev, lane=lane)
+            if need_w:
+                if w_direct is not None and cp == i:
+                    # dW += ... straight into the flat gradient slab (split-K reduce / epilogue adds the old value)
+                    check(
+                        L.so_conv2d_wgrad_acc(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), w_direct.grad.data_ptr(), n, h, wd,
+                                              cp, o, r, s, stride, pad, wsl.data_ptr(), wsl.numel() * 4, _stream()),
+                        "conv2d_wgrad_acc",
+                    )
+                else:
+                    dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
+                    check(
+                        L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
+                                          stride, pad, wsl.data_ptr(), wsl.numel() * 4, _stream()),
+                        "conv2d_wgrad",
+                    )
+                    if w_direct is not None:  # channel-padded first layer: un-pad while accumulating into the slab
+                        check(L.so_copy2d(dwp.data_ptr(), cp, i, w_direct.grad.data_ptr(), i, i, o * r * s, 1, _stream()), "copy2d")
+                        keep.append(dwp)
+                    else:
+                        if cp != i:
+                            dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
+                            check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
+                            keep.append(dwp)
+                            dwp = dwd
+                        dw_ = dwp.permute(0, 3, 1, 2)
+            if need_b:
+                if b_direct is not None:
+                    wsb = workspace(dev, L.so_colsum_ws_floats(rows_out, o) * 4, lane=lane + 2)
+                    check(L.so_colsum(dy.data_ptr(), _ld(dy), rows_out, o, b_direct.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
+                else:
+                    db_ = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
+            return dw_, db_
+
+        keep = []  # temporaries of the side stream must outlive the join
+        fork = None
+        if CONCURRENT_WGRAD and ctx.needs_input_grad[0] and (need_w or need_b):
+            fork = _SideStream(dev)
+            with fork:
+                dw, db = weight_grads(lane=1)
         if ctx.needs_input_grad[0]:
+            ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
             wt = _ihwo(w)  # transposed weights: both GEMM operands k-contiguous (same mode as the forward conv)
             check(
@@ -260,37 +342,10 @@ class _Conv2dFn(torch.autograd.Function):
                 "conv2d_dgrad_t",
             )
             dx = dxp if cp == i else dxp[:, :i]
-        w_direct, b_direct = ctx.direct
-        if ctx.needs_input_grad[1]:
-            if w_direct is not None and cp == i:
-                # dW += ... straight into the flat gradient slab (split-K reduce / epilogue adds the old value)
-                check(
-                    L.so_conv2d_wgrad_acc(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), w_direct.grad.data_ptr(), n, h, wd,
-                                          cp, o, r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                    "conv2d_wgrad_acc",
-                )
-            else:
-                dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
-                check(
-                    L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
-                                      stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                    "conv2d_wgrad",
-                )
-                if w_direct is not None:  # channel-padded first layer: un-pad while accumulating into the slab
-                    check(L.so_copy2d(dwp.data_ptr(), cp, i, w_direct.grad.data_ptr(), i, i, o * r * s, 1, _stream()), "copy2d")
-                else:
-                    if cp != i:
-                        dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
-                        check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
-                        dwp = dwd
-                    dw = dwp.permute(0, 3, 1, 2)
-        if has_bias and ctx.needs_input_grad[2]:
-            if b_direct is not None:
-                need = L.so_colsum_ws_floats(rows_out, o) * 4
-                wsb = workspace(dev, need)
-                check(L.so_colsum(dy.data_ptr(), _ld(dy), rows_out, o, b_direct.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
-            else:
-                db = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
+        if fork is not None:
+            fork.join()
+        elif need_w or need_b:
+            dw, db = weight_grads(lane=0)
         return dx, dw, db, None, None, None
 
 
