@@ -42,6 +42,12 @@ int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, 
                     int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
                     float act_param, float* ws, long long ws_bytes, void* stream);
 
+/* same with output-channel zero padding: Ko columns are written, only the first Kw have weights/bias (the
+ * rest are act(0)); used when a channel count is not a multiple of 4 (n_frames_total > 1: ngf = 134, 167...). */
+int so_conv2d_fprop_padded(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                           int Nb, int H, int W, int C, int Ko, int Kw, int R, int S, int stride, int pad,
+                           int act, float act_param, float* ws, long long ws_bytes, void* stream);
+
 /* input gradient of the same convolution (autograd of the call sites above): dx: [Nb*H*W][C]. */
 int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nb, int H,
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,

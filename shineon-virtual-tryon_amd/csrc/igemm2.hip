@@ -56,6 +56,7 @@ struct SoIgemm {
   int act;
   float act_param;
   int splitk, ktps, nclass;
+  int nbias;         // bias entries available (columns >= nbias get no bias: zero channel padding)
   long long sa, sb, sc, sres;  // GEMM batch strides in elements
 };
 
@@ -76,7 +77,7 @@ __device__ __forceinline__ void so_divmod(unsigned x, unsigned d, float inv, uns
 
 __device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long long res_off, int n) {
   if (p.alpha) v *= p.alpha[0];
-  if (p.bias) v += p.bias[n];
+  if (p.bias && n < p.nbias) v += p.bias[n];
   if (p.res) v += p.res[res_off + n];
   return so_actf(p.act, v, p.act_param);
 }
@@ -810,12 +811,16 @@ int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
   return n;
 }
 
-int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
-                    int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
-                    float act_param, float* ws, long long ws_bytes, void* stream) {
+// Ko output columns are computed and written; only the first Kw of them have weight rows / bias entries, the
+// remaining columns come out as act(0) (zero channel padding of the output for channel counts that are not a
+// multiple of 4: the weight descriptor simply ends after Kw rows and the hardware returns zeros beyond it).
+int so_conv2d_fprop_padded(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                           int Nb, int H, int W, int C, int Ko, int Kw, int R, int S, int stride, int pad,
+                           int act, float act_param, float* ws, long long ws_bytes, void* stream) {
   if ((C & 3) || (ldx & 3) || !so_aligned16(x) || !so_aligned16(w)) return SO_ERR_ALIGN;
+  if (Kw > Ko || Kw <= 0) return SO_ERR_SHAPE;
   SoIgemm p = {};
-  p.a = x; p.b = w; p.c = y; p.ws = ws; p.bias = bias;
+  p.a = x; p.b = w; p.c = y; p.ws = ws; p.bias = bias; p.nbias = Kw;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
   p.Ho = (H + 2 * pad - R) / stride + 1;
   p.Wo = (W + 2 * pad - S) / stride + 1;
@@ -823,12 +828,20 @@ int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, 
   p.M = Nb * p.Ho * p.Wo; p.N = Ko; p.K = R * S * C;
   p.lda = ldx; p.ldb = p.K; p.ldc = ldy; p.ldres = 0;
   p.a_bytes = so_extent((long long)Nb * H * W, ldx);
-  p.b_bytes = so_extent(Ko, p.K);
+  p.b_bytes = so_extent(Kw, p.K);
   if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = act; p.act_param = act_param; p.nclass = 1;
   return so_launch<MODE_FPROP, false, false>(p, ws_bytes, (hipStream_t)stream);
 }
 
+int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
+                    float act_param, float* ws, long long ws_bytes, void* stream) {
+  return so_conv2d_fprop_padded(x, ldx, w, bias, y, ldy, Nb, H, W, C, Ko, Ko, R, S, stride, pad, act, act_param, ws,
+                                ws_bytes, stream);
+}
+
+// Input gradient reading the OHWI weights in place (KC x MC mode: no transposed copy needed).
 int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int Nb, int H,
                     int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                     long long ws_bytes, void* stream) {
@@ -932,6 +945,7 @@ int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A,
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.sa = sa; p.sb = sb; p.sc = sc; p.sres = sres;
   p.act = act; p.act_param = act_param; p.nclass = batch;
+  p.nbias = N;
   p.stride = 1;
   p.a_bytes = so_extent(transa ? K : M, lda);
   p.b_bytes = so_extent(transb ? N : K, ldb);

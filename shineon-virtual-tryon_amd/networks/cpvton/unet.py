@@ -86,6 +86,10 @@ class UnetSkipConnectionBlock(nn.Module):
         else:
             down = [down_activation, downconv, downnorm]
         up = [up_activation, HipUpsample2x(), upconv, upnorm]
+        norm_kind = "always" if norm_layer is HipInstanceNorm2d else "train"
+        upconv.zero_bias_grad = norm_kind                      # upconv -> upnorm
+        if not outermost and not innermost:
+            downconv.zero_bias_grad = norm_kind                # downconv -> downnorm
         if self_attn:
             down.append(SelfAttention(inner_nc, "relu"))
             up.append(SelfAttention(outer_nc, "relu"))

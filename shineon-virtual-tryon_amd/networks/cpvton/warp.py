@@ -65,6 +65,8 @@ class FeatureRegression(nn.Module):
             HipConv2d(256, 128, kernel_size=3, stride=1, padding=1), HipBatchNorm2d(128), HipReLU(),
             HipConv2d(128, 64, kernel_size=3, stride=1, padding=1), HipBatchNorm2d(64), HipReLU(),
         )
+        for conv_idx in (0, 3, 6, 9):  # Conv -> BatchNorm directly: zero bias gradient in training mode
+            self.conv[conv_idx].zero_bias_grad = "train"
         self.linear = HipLinearCHW(64 * 4 * 3, output_dim, apply_tanh=True)  # tanh fused (warp.py:88,98)
         self.tanh = nn.Identity()
 

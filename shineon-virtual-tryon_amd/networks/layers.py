@@ -28,6 +28,10 @@ class HipConv2d(nn.Module):
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.fuse_relu = fuse_relu
+        # Set by the owning block when this conv feeds an Instance/BatchNorm directly: the bias gradient is then
+        # analytically zero (the norm removes per-channel constants) and its reduction is skipped.
+        # "always": InstanceNorm follows; "train": BatchNorm follows (true only with batch statistics).
+        self.zero_bias_grad = None
         self.weight = _ohwi_param(out_channels, in_channels, kernel_size, kernel_size)
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
@@ -42,8 +46,9 @@ class HipConv2d(nn.Module):
             init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
+        zbg = self.zero_bias_grad == "always" or (self.zero_bias_grad == "train" and self.training)
         return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding,
-                          ops.ACT_RELU if self.fuse_relu else ops.ACT_NONE)
+                          ops.ACT_RELU if self.fuse_relu else ops.ACT_NONE, zero_bias_grad=zbg)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "

@@ -242,59 +242,76 @@ def _direct_grad_ok(p, ohwi):
 # ------------------------------------------------------------------------------------------------
 # Conv2d
 # ------------------------------------------------------------------------------------------------
+def _pad_rows(w_ohwi, o_pad):
+    """(O, R, S, C) -> (O_pad, R, S, C) with zero rows appended (output-channel padding of the weights)."""
+    o, r, s, c = w_ohwi.shape
+    if o_pad == o:
+        return w_ohwi
+    out = torch.empty((o_pad, r, s, c), dtype=torch.float32, device=w_ohwi.device)
+    fill_(out, 0.0)
+    check(lib().so_copy2d(w_ohwi.data_ptr(), c, c, out.data_ptr(), c, c, o * r * s, 0, _stream()), "copy2d")
+    return out
+
+
 class _Conv2dFn(torch.autograd.Function):
+    """Conv2d on the MFMA implicit-GEMM engine.  Channel counts that are not multiples of 4 (n_frames_total > 1
+    gives ngf = 134, 167, ...) are handled by zero padding: input channels of x / w are padded to cp, output
+    channels are computed as op = ceil4(o) columns of which the last op - o are exactly zero."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act):
+    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad):
         L = lib()
         o, i, r, s = weight.shape
-        cp = (i + 3) // 4 * 4
+        cp, op = (i + 3) // 4 * 4, (o + 3) // 4 * 4
         xr = to_rows(x, cpad=cp) if cp != i else _dense_rows(x)
         w = _ohwi(weight, cpad=cp)
         n, _, h, wd = xr.shape
         ho = (h + 2 * pad - r) // stride + 1
         wo = (wd + 2 * pad - s) // stride + 1
-        y = nhwc_empty(n, ho, wo, o, x.device)
+        y = nhwc_empty(n, ho, wo, op, x.device)
         ws = workspace(x.device)
         check(
-            L.so_conv2d_fprop(
+            L.so_conv2d_fprop_padded(
                 xr.data_ptr(), _ld(xr), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                y.data_ptr(), o, n, h, wd, cp, o, r, s, stride, pad, act, 0.0,
+                y.data_ptr(), op, n, h, wd, cp, op, o, r, s, stride, pad, act, 0.0,
                 ws.data_ptr(), ws.numel() * 4, _stream(),
             ),
             "conv2d_fprop",
         )
         ctx.save_for_backward(xr, w, y if act != ACT_NONE else None)
-        ctx.cfg = (stride, pad, act, i, cp, bias is not None, tuple(weight.shape))
+        ctx.cfg = (stride, pad, act, i, cp, op, bias is not None, tuple(weight.shape), zero_bias_grad)
         # parameters whose .grad is a view of the optimizer's flat slab get their gradient accumulated in place
         ctx.direct = (weight if _direct_grad_ok(weight, ohwi=True) else None,
                       bias if bias is not None and _direct_grad_ok(bias, ohwi=False) else None)
-        return y
+        return y if op == o else y[:, :o]
 
     @staticmethod
     def backward(ctx, dy):
         L = lib()
         xr, w, y = ctx.saved_tensors
-        stride, pad, act, i, cp, has_bias, wshape = ctx.cfg
+        stride, pad, act, i, cp, op, has_bias, wshape, zero_bias_grad = ctx.cfg
         o, _, r, s = wshape
         n, _, h, wd = xr.shape
-        dy = _dense_rows(dy)
+        dy = to_rows(dy, cpad=op) if op != o else _dense_rows(dy)  # [rows][op], pad columns zero
         dev = dy.device
         rows_out = dy.shape[0] * dy.shape[2] * dy.shape[3]
         if act != ACT_NONE:
-            g = nhwc_empty(dy.shape[0], dy.shape[2], dy.shape[3], o, dev)
-            check(L.so_act_bwd(y.data_ptr(), _ld(y), dy.data_ptr(), _ld(dy), g.data_ptr(), o, rows_out, o, act, 0.0, _stream()), "act_bwd")
+            g = nhwc_empty(dy.shape[0], dy.shape[2], dy.shape[3], op, dev)
+            check(L.so_act_bwd(y.data_ptr(), op, dy.data_ptr(), _ld(dy), g.data_ptr(), op, rows_out, op, act, 0.0, _stream()), "act_bwd")
             dy = g
         dx = dw = db = None
         w_direct, b_direct = ctx.direct
         need_w = ctx.needs_input_grad[1]
         need_b = has_bias and ctx.needs_input_grad[2]
+        plain = cp == i and op == o  # no channel padding anywhere: kernels can write the slab layout directly
+        keep = []  # temporaries of the side stream must outlive the join
 
         def weight_grads(lane):
             """dW (+ d bias) on the current stream with the scratch slab of `lane`."""
             dw_, db_ = None, None
             wsl = workspace(dev, lane=lane)
             if need_w:
-                if w_direct is not None and cp == i:
+                if w_direct is not None and plain:
                     # dW += ... straight into the flat gradient slab (split-K reduce / epilogue adds the old value)
                     check(
                         L.so_conv2d_wgrad_acc(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), w_direct.grad.data_ptr(), n, h, wd,
@@ -302,31 +319,40 @@ class _Conv2dFn(torch.autograd.Function):
                         "conv2d_wgrad_acc",
                     )
                 else:
-                    dwp = torch.empty((o, r, s, cp), dtype=torch.float32, device=dev)
+                    dwp = torch.empty((op, r, s, cp), dtype=torch.float32, device=dev)
                     check(
-                        L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, o, r, s,
+                        L.so_conv2d_wgrad(dy.data_ptr(), _ld(dy), xr.data_ptr(), _ld(xr), dwp.data_ptr(), n, h, wd, cp, op, r, s,
                                           stride, pad, wsl.data_ptr(), wsl.numel() * 4, _stream()),
                         "conv2d_wgrad",
                     )
-                    if w_direct is not None:  # channel-padded first layer: un-pad while accumulating into the slab
+                    keep.append(dwp)
+                    # the first o*r*s rows are the real output channels; drop the padded input channels while copying
+                    if w_direct is not None:
                         check(L.so_copy2d(dwp.data_ptr(), cp, i, w_direct.grad.data_ptr(), i, i, o * r * s, 1, _stream()), "copy2d")
-                        keep.append(dwp)
-                    else:
-                        if cp != i:
-                            dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
-                            check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
-                            keep.append(dwp)
-                            dwp = dwd
+                    elif plain:
                         dw_ = dwp.permute(0, 3, 1, 2)
+                    else:
+                        dwd = torch.empty((o, r, s, i), dtype=torch.float32, device=dev)
+                        check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
+                        dw_ = dwd.permute(0, 3, 1, 2)
             if need_b:
-                if b_direct is not None:
+                if zero_bias_grad:
+                    # a bias in front of Instance/BatchNorm has an analytically zero gradient (the norm removes any
+                    # per-channel constant); the reference computes round-off noise there.  Write the exact zero.
+                    if b_direct is None:
+                        db_ = fill_(torch.empty(o, dtype=torch.float32, device=dev), 0.0)
+                elif b_direct is not None and op == o:
                     wsb = workspace(dev, L.so_colsum_ws_floats(rows_out, o) * 4, lane=lane + 2)
                     check(L.so_colsum(dy.data_ptr(), _ld(dy), rows_out, o, b_direct.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
                 else:
-                    db_ = _colsum(dy.data_ptr(), _ld(dy), rows_out, o, dev)
+                    dbp = _colsum(dy.data_ptr(), _ld(dy), rows_out, op, dev)
+                    if b_direct is not None:
+                        check(L.so_axpby(dbp.data_ptr(), 1.0, b_direct.grad.data_ptr(), 1.0, o, _stream()), "axpby")
+                        keep.append(dbp)
+                    else:
+                        db_ = dbp[:o]
             return dw_, db_
 
-        keep = []  # temporaries of the side stream must outlive the join
         fork = None
         if CONCURRENT_WGRAD and ctx.needs_input_grad[0] and (need_w or need_b):
             fork = _SideStream(dev)
@@ -335,9 +361,9 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
-            wt = _ihwo(w)  # transposed weights: both GEMM operands k-contiguous (same mode as the forward conv)
+            wt = _ihwo(_pad_rows(w, op))  # transposed weights: both GEMM operands k-contiguous (same mode as fprop)
             check(
-                L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, o, r, s,
+                L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op, r, s,
                                     stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
                 "conv2d_dgrad_t",
             )
@@ -346,12 +372,13 @@ class _Conv2dFn(torch.autograd.Function):
             fork.join()
         elif need_w or need_b:
             dw, db = weight_grads(lane=0)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE):
-    """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA."""
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, act)
+def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False):
+    """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
+    output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed."""
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -561,9 +588,15 @@ class _SelfAttentionFn(torch.autograd.Function):
         n = h * w
         d = wq.shape[0]
         dev = x.device
-        if c % 4 or d % 4 or n % 4:
-            raise RuntimeError("self-attention kernels need C, C//8 and H*W to be multiples of 4")
+        if c % 4 or n % 4:
+            raise RuntimeError("self-attention kernels need C and H*W to be multiples of 4")
         wq2, wk2, wv2 = (_ohwi(t).reshape(t.shape[0], c) for t in (wq, wk, wv))
+        d_true = d
+        if d % 4:  # e.g. C = 1336 -> d = 167: zero-pad the query/key projections to a multiple of 4 (adds 0 to Q.K)
+            d = (d + 3) // 4 * 4
+            wq2, wk2 = (_pad_rows(t.reshape(d_true, 1, 1, c), d).reshape(d, c) for t in (wq2, wk2))
+            pad_vec = lambda t: torch.cat([t.detach(), torch.zeros(d - d_true, dtype=torch.float32, device=dev)])
+            bq, bk = pad_vec(bq), pad_vec(bk)
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         q, k, v = f(b * n, d), f(b * n, d), f(b * n, c)
         ldx = _ld(x)
@@ -583,7 +616,7 @@ class _SelfAttentionFn(torch.autograd.Function):
         out = nhwc_empty(b, h, w, c, dev)
         check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
         ctx.save_for_backward(x, wq2, wk2, wv2, q, k, v, a, o, gamma)
-        ctx.shapes = (tuple(wq.shape), tuple(wk.shape), tuple(wv.shape))
+        ctx.shapes = (tuple(wq.shape), tuple(wk.shape), tuple(wv.shape), d_true)
         return out
 
     @staticmethod
@@ -629,8 +662,8 @@ class _SelfAttentionFn(torch.autograd.Function):
         dbq = _colsum(dq.data_ptr(), d, b * n, d, dev)
         dbk = _colsum(dk.data_ptr(), d, b * n, d, dev)
         dbv = _colsum(dv.data_ptr(), c, b * n, c, dev)
-        sq, sk, sv = ctx.shapes
-        return dx, dwq.view(sq), dbq, dwk.view(sk), dbk, dwv.view(sv), dbv, dgamma
+        sq, sk, sv, d_true = ctx.shapes
+        return (dx, dwq[:d_true].view(sq), dbq[:d_true], dwk[:d_true].view(sk), dbk[:d_true], dwv.view(sv), dbv, dgamma)
 
 
 def self_attention(x, wq, bq, wk, bk, wv, bv, gamma):

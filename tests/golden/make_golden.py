@@ -187,6 +187,35 @@ def gen_unet(out):
         print(f"unet_mask_{tag}.npz", {k: float(v) for k, v in data.items() if k.startswith("log:")})
 
 
+def gen_unet_nframes(out):
+    """n_frames_total = 3 with flow warping: ngf = int(64 * (ln 3 + 1)) = 134 (channel counts that are NOT multiples
+    of 4), 5 output channels per frame, previous generated frame warped by Resample2d (the oracle's stand-in, since
+    the flownet2 submodule is empty) and blended with the flow mask.  128 x 64 images keep the fixture small."""
+    from models.unet_mask_model import UnetMaskModel
+
+    hp = hp_namespace(n_frames_total=3, flow_warp=True, activation="gelu", fine_height=128, fine_width=64)
+    torch.manual_seed(0)
+    model = UnetMaskModel(hp)
+    model.load_state_dict(procedural_state_dict(shapes_of(model.state_dict())))
+    model.train()
+    batch = synthetic_batch(2, "cpu", height=128, width=64, n_frames=3, smooth=True)
+    res = model.training_step(batch, 0)
+    res.minimize.backward()
+    data = {"state_keys": np.array(list(model.state_dict().keys())),
+            "state_shapes": np.array([str(tuple(v.shape)) for v in model.state_dict().values()])}
+    for k, v in res.logs.items():
+        data["log:" + k] = np.float64(v.item())
+    for name, ts in (("p_rendered", model.p_rendereds), ("tryon_mask", model.tryon_masks), ("p_tryon", model.p_tryons),
+                     ("flow_mask", model.flow_masks)):
+        t = torch.cat(list(ts), 1)
+        data[name + "_s4"] = strided(t, 4)
+        data[name + "_cs"] = checksums(t)
+    for k, v in grad_checksums(model.unet).items():
+        data["gcs:unet." + k] = v
+    np.savez_compressed(os.path.join(out, "unet_mask_n3_flow.npz"), **data)
+    print("unet_mask_n3_flow.npz", {k: float(v) for k, v in data.items() if k.startswith("log:")})
+
+
 def gen_ops(out):
     """Per-op goldens from the reference's nn.Modules at small sizes (full tensors)."""
     from models.networks.attention.sagan import SelfAttention
@@ -236,3 +265,5 @@ if __name__ == "__main__":
         gen_warp(HERE)
     if "unet" in which:
         gen_unet(HERE)
+    if "nframes" in which or not sys.argv[1:]:
+        gen_unet_nframes(HERE)
