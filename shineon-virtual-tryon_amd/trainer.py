@@ -47,14 +47,29 @@ class GradientAllReducer:
         self.buckets = [flat_grads[i:min(i + step, n)] for i in range(0, n, step)]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+        self._works = None
+
+    def start(self):
+        """Issue the asynchronous all-reduce of every bucket (RCCL runs on its own stream, ordered after the work
+        already queued on the current stream), so that it overlaps whatever is launched next."""
+        if self.world > 1:
+            self._works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+
+    def finish(self):
+        """Make the current stream wait for the reduction; returns the factor the optimizer must scale the
+        (summed) gradients by: 1 / world."""
+        if self._works is not None:
+            for w in self._works:
+                w.wait()
+            self._works = None
+        return 1.0 / self.world
+
     def all_reduce(self):
-        """Returns the factor the optimizer must scale gradients by (1 / world)."""
+        """start() + finish(): returns the factor the optimizer must scale gradients by (1 / world)."""
         if self.world == 1:
             return 1.0
-        works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
-        for w in works:
-            w.wait()
-        return 1.0 / self.world
+        self.start()
+        return self.finish()
 
 
 def broadcast_buffers(model, src=0):

@@ -172,6 +172,13 @@ torch.manual_seed(rank)
 flat = torch.full((5000,), float(rank + 1))
 scale = GradientAllReducer(flat, n_buckets=4).all_reduce()
 assert abs(scale - 0.5) < 1e-12 and torch.allclose(flat * scale, torch.full((5000,), 1.5)), flat[:3]
+# split start()/finish() form used to overlap the transfer with the next model's graph
+flat2 = torch.arange(3000, dtype=torch.float32) * (rank + 1)
+red = GradientAllReducer(flat2, n_buckets=3)
+red.start()
+scale2 = red.finish()
+assert torch.allclose(flat2 * scale2, torch.arange(3000, dtype=torch.float32) * 1.5)
+assert red.finish() == 0.5  # idempotent when nothing is pending
 m = torch.nn.Linear(4, 4)
 broadcast_parameters(m)
 w = [torch.zeros_like(m.weight) for _ in range(2)]
