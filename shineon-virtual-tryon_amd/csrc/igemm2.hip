@@ -476,6 +476,58 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[0][r];
   }
   const bool to_ws = p.splitk > 1;
+  // Wide path: each 32x32 accumulator tile is transposed through a wave-private LDS patch so that a lane owns
+  // four consecutive columns of one row and issues 16-byte stores (8 rows x 128 B per instruction) instead of
+  // sixteen 4-byte stores per tile.  Needs 16-byte aligned rows; otherwise the scalar path below is used.
+  const bool wide = (p.N & 3) == 0 &&
+                    (to_ws || ((p.ldc & 3) == 0 && (((uintptr_t)p.c) & 15) == 0 && (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
+                               (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0 &&
+                                           (MODE != MODE_GEMM || (p.sres & 3) == 0)))));
+  if (wide) {
+    float* stg = smem + wave * (32 * LDK);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDK + li] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (lane >> 3) + 8 * q, col4 = (lane & 7) * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * LDK + col4);
+          const int m = m0 + wm * WTM + i * 32 + row;
+          const int n = n0 + wn * WTN + j * 32 + col4;
+          if (m < p.M && n < p.N) {
+            if (to_ws) {
+              *reinterpret_cast<f32x4*>(p.ws + ((long long)blockIdx.z * p.M + m) * p.N + n) = v;
+            } else {
+              long long off, roff;
+              so_row_offset<MODE>(p, cls, m, off, roff);
+              if (off >= 0) {
+                if (p.alpha) { const float al = p.alpha[0]; v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al; }
+                if (p.bias) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) if (n + k < p.nbias) v[k] += p.bias[n + k];
+                }
+                if (p.res) {
+                  const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + roff + n);
+                  v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+                }
+                if (p.act != SO_ACT_NONE) {
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
+                }
+                *reinterpret_cast<f32x4*>(p.c + off + n) = v;
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
