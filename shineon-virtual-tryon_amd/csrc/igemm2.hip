@@ -15,10 +15,12 @@
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  K may be permuted freely as long as A and B agree,
 //     so a lane-half reads FOUR consecutive k with one ds_read_b128 and feeds four MFMAs
 //     (k = kbase + 4*(lane>>5) + t for MFMA t).
-//   * two operand staging modes in LDS:
-//       KC ("k-contiguous")  : tile [rows][32 k], row pitch 36 floats -> conflict-free ds_read_b128
-//       MC ("mn-contiguous") : tile [32 k][rows]                      -> conflict-free ds_read_b32
-//     FPROP = KC x KC, DGRAD = KC x MC (weights read in place, no transposed copy), WGRAD = MC x MC.
+//   * LDS tiles are always [rows][32 k], row pitch 36 floats -> conflict-free ds_read_b128 for both operands.
+//     Two ways of getting there from HBM:
+//       KC ("k-contiguous" memory)  : the 16-byte quad a lane loads is a run of k -> stored as is
+//       MC ("mn-contiguous" memory) : the quad is a run of rows at one k; a lane loads the quads of 1/2/4
+//                                     consecutive k and writes them transposed (4 x ds_write_b32/b64/b128)
+//     FPROP = KC x KC, DGRAD = KC x KC on transposed weights (or KC x MC in place), WGRAD = MC x MC.
 //   * BRANCH-FREE staging: operands are read through buffer descriptors; a lane that must see a zero (conv
 //     padding, ragged tile edge, K tail) issues the same buffer_load with an out-of-range offset and the
 //     hardware returns 0.  The K-tile body is one straight-line block, so the scheduler can slot the address
@@ -126,6 +128,36 @@ __device__ __forceinline__ f32x4 so_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return r;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// MC staging: a thread holds J quads q[j] = operand[k0 + j][m4 .. m4+3] (memory is contiguous along m/n, so the
+// global loads stay 16-byte and coalesced along m) and leaves them K-CONTIGUOUS in LDS: row m4+i receives the J
+// values of k0 .. k0+J-1 in one ds_write (b128 / b64 / b32 for J = 4 / 2 / 1), so that the MFMA side reads every
+// operand with ds_read_b128.  Such tiles use an unpadded 32-float row whose eight 16-byte k-quads are XOR-swizzled
+// with so_swz(row): found by exhaustive search over bit-linear swizzles against the gfx950 bank/lane-group rules,
+// it makes the ds_read_b128 of a 32-row tile and the transposed b128 stores conflict-free (b64/b32: 2-way, free).
+__device__ __forceinline__ int so_swz(int row) {
+  return ((row >> 2) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 1) ^ (row >> 4)) & 1) << 2);
+}
+
+template <int J>
+__device__ __forceinline__ void so_store_transposed(float* tile, const int (&addr)[4], const f32x4 (&q)[J]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* d = tile + addr[i];
+    if constexpr (J == 4) {
+      f32x4 w; w[0] = q[0][i]; w[1] = q[1][i]; w[2] = q[2][i]; w[3] = q[3][i];
+      *reinterpret_cast<f32x4*>(d) = w;
+    } else if constexpr (J == 2) {
+      f32x2 w; w[0] = q[0][i]; w[1] = q[1][i];
+      *reinterpret_cast<f32x2*>(d) = w;
+    } else {
+      static_assert(J == 1, "1, 2 or 4 quads per thread");
+      d[0] = q[0][i];
+    }
+  }
+}
+
 // NW = waves per block: 4 (2x2 wave grid) or 8 (2x4, BN = 128 only: twice the waves per SIMD for the same LDS
 // footprint, which hides the staging bubbles of the large tiles).
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
@@ -133,8 +165,9 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
   constexpr int NT = NW * 64;
   constexpr int LDK = 36;  // KC row pitch: 144 B -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots
-  constexpr int A_STAGE = A_MC ? BK * BM : BM * LDK;
-  constexpr int B_STAGE = B_MC ? BK * BN : BN * LDK;
+  constexpr int LDA = A_MC ? 32 : LDK, LDB = B_MC ? 32 : LDK;  // MC tiles: unpadded + swizzled (so_swz)
+  constexpr int A_STAGE = BM * LDA;
+  constexpr int B_STAGE = BN * LDB;
   constexpr int WGN = NW / 2;                          // waves along N
   constexpr int WTM = BM / 2, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -142,7 +175,6 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int RPP = NT / 8;                          // KC mode: tile rows covered per pass
   constexpr int AJ = BM / RPP, BJ = BN / RPP;          // 16-byte quads staged per thread per K tile
   constexpr int AQPR = BM / 4, BQPR = BN / 4;          // MC mode: quads per k-row
-  constexpr int ARPP = NT / AQPR, BRPP = NT / BQPR;    // MC mode: k-rows covered per pass
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -227,6 +259,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   }
   const int a_mq = tid % AQPR, a_kr = tid / AQPR;  // MC mapping
   const int b_mq = tid % BQPR, b_kr = tid / BQPR;
+  int a_st[4], b_st[4];  // MC: LDS offsets of the four transposed rows this thread writes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ar = a_mq * 4 + i, br = b_mq * 4 + i;
+    a_st[i] = ar * 32 + ((((a_kr * AJ) >> 2) ^ so_swz(ar)) << 2) + ((a_kr * AJ) & 3);
+    b_st[i] = br * 32 + ((((b_kr * BJ) >> 2) ^ so_swz(br)) << 2) + ((b_kr * BJ) & 3);
+  }
   // B operand, KC (weights / plain rows): element offset of each row, -1 if out of range
   int b_row[BJ];
   (void)b_row;
@@ -254,6 +293,23 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   const int nkt = (p.K + BK - 1) / BK;
   const int kt_begin = split * p.ktps;
   const int kt_end = (kt_begin + p.ktps > nkt) ? nkt : kt_begin + p.ktps;
+
+  // WGRAD B: output pixel (n, ho, wo) of the thread's next k row, advanced incrementally (no per-quad division)
+  int wg_n = 0, wg_ho = 0, wg_wo = 0, wg_dw = 0, wg_dh = 0, wg_dn = 0;
+  (void)wg_n; (void)wg_ho; (void)wg_wo; (void)wg_dw; (void)wg_dh; (void)wg_dn;
+  if constexpr (MODE == MODE_WGRAD) {
+    const int kk = kt_begin * BK + b_kr * BJ;
+    const int hw = p.Ho * p.Wo;
+    wg_n = kk / hw;
+    const int rem = kk - wg_n * hw;
+    wg_ho = rem / p.Wo;
+    wg_wo = rem - wg_ho * p.Wo;
+    const int adv = BK - (BJ - 1);          // from the last quad of a tile to the first quad of the next
+    const int q1 = adv / p.Wo;
+    wg_dw = adv - q1 * p.Wo;
+    wg_dn = q1 / p.Ho;
+    wg_dh = q1 - wg_dn * p.Ho;
+  }
 
   // Issue the (branch-free) global loads of K tile `kt` into ra/rb.  Tiles at or beyond kt_end read as zeros
   // without touching memory (every lane goes out of range), which lets the main loop run without tail branches.
@@ -297,7 +353,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       const bool colok = col < p.M;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int kk = k0 + a_kr + ARPP * j;
+        const int kk = k0 + a_kr * AJ + j;
         const bool ok = colok & (kk < Klim);
         ra[j] = so_bload(rA, ok ? (unsigned)(kk * p.lda + col) * 4u : SO_OOB);
       }
@@ -326,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       const int col = n0 + b_mq * 4;
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        const int kk = k0 + b_kr + BRPP * j;
+        const int kk = k0 + b_kr * BJ + j;
         if constexpr (MODE == MODE_DGRAD) {
           unsigned tapi, ko, tr, ts;
           so_divmod((unsigned)kk, (unsigned)p.Ko, invKo, tapi, ko);
@@ -335,13 +391,28 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const bool ok = (kk < Klim) & (col < p.N);
           rb[j] = so_bload(rB, ok ? (unsigned)(((int)ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
         } else if constexpr (MODE == MODE_WGRAD) {
-          unsigned n, rem, ho, wo;
-          so_divmod((unsigned)kk, (unsigned)(p.Ho * p.Wo), invHWo, n, rem);
-          so_divmod(rem, (unsigned)p.Wo, invWo, ho, wo);
-          const int hi = (int)ho * p.stride - p.pad + w_r;
-          const int wi = (int)wo * p.stride - p.pad + w_s;
+          // (wg_n, wg_ho, wg_wo) = output pixel of k row kk, carried from quad to quad and from tile to tile
+          const int hi = wg_ho * p.stride - p.pad + w_r;
+          const int wi = wg_wo * p.stride - p.pad + w_s;
           const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          rb[j] = so_bload(rB, ok ? (unsigned)((((int)n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
+          rb[j] = so_bload(rB, ok ? (unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
+          if (j + 1 < BJ) {  // next k row = next output pixel
+            wg_wo += 1;
+            const bool cw = wg_wo == p.Wo;
+            wg_wo = cw ? 0 : wg_wo;
+            wg_ho += cw ? 1 : 0;
+            const bool ch = wg_ho == p.Ho;
+            wg_ho = ch ? 0 : wg_ho;
+            wg_n += ch ? 1 : 0;
+          } else {           // first k row of the next tile: 32 - (BJ - 1) pixels ahead
+            wg_wo += wg_dw;
+            const bool cw = wg_wo >= p.Wo;
+            wg_wo -= cw ? p.Wo : 0;
+            wg_ho += wg_dh + (cw ? 1 : 0);
+            const bool ch = wg_ho >= p.Ho;
+            wg_ho -= ch ? p.Ho : 0;
+            wg_n += wg_dn + (ch ? 1 : 0);
+          }
         } else {
           const bool ok = (kk < Klim) & (col < p.N);
           rb[j] = so_bload(rB, ok ? (unsigned)(kk * p.ldb + col) * 4u : SO_OOB);
@@ -357,9 +428,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j)
         *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = ra[j];
     } else {
-#pragma unroll
-      for (int j = 0; j < AJ; ++j)
-        *reinterpret_cast<f32x4*>(as + (a_kr + ARPP * j) * BM + a_mq * 4) = ra[j];
+      so_store_transposed<AJ>(as, a_st, ra);
     }
   };
   auto store_b = [&](int st) {
@@ -369,9 +438,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < BJ; ++j)
         *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = rb[j];
     } else {
-#pragma unroll
-      for (int j = 0; j < BJ; ++j)
-        *reinterpret_cast<f32x4*>(bs + (b_kr + BRPP * j) * BN + b_mq * 4) = rb[j];
+      so_store_transposed<BJ>(bs, b_st, rb);
     }
   };
 
@@ -400,23 +467,17 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if constexpr (!A_MC) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(as + (wm * WTM + i * 32 + li) * LDK + kc * 8 + lh * 4);
-          af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) af[i][t] = as[(kc * 8 + lh * 4 + t) * BM + wm * WTM + i * 32 + li];
-        }
+        const int row = wm * WTM + i * 32 + li;
+        const int off = A_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(as + off);
+        af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (!B_MC) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(bs + (wn * WTN + j * 32 + li) * LDK + kc * 8 + lh * 4);
-          bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kc * 8 + lh * 4 + t) * BN + wn * WTN + j * 32 + li];
-        }
+        const int row = wn * WTN + j * 32 + li;
+        const int off = B_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bs + off);
+        bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
       }
       if constexpr (KS == 2) {
 #pragma unroll
@@ -646,8 +707,8 @@ static hipEvent_t so_prof_event() {
 
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
-  constexpr int A_STAGE = A_MC ? 32 * BM : BM * 36;
-  constexpr int B_STAGE = B_MC ? 32 * BN : BN * 36;
+  constexpr int A_STAGE = BM * (A_MC ? 32 : 36);
+  constexpr int B_STAGE = BN * (B_MC ? 32 : 36);
   constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
   auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN, NW>;
   static bool attr_set = false;
