@@ -35,7 +35,7 @@ from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
-             for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "-", "-")]
+             for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
 
 
 def hparams(**kw):

@@ -33,6 +33,7 @@
 //   * fused epilogue: alpha (device scalar, attention gamma) * acc + bias[n] + residual, then activation.
 #include "common.h"
 #include "../../include/shineon_hip.h"
+#include "thin.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -685,7 +686,7 @@ static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
 // Events are recorded on the launch stream around the main kernel only (not the split-K reduce).
 struct SoProfRec {
   hipEvent_t e0, e1;
-  int key;  // MODE * 4 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128)
+  int key;  // MODE * 8 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128, 4/5: 8-wave tiles, 6: thin.hip)
   double flops;
   int M, N, K, nclass, splitk;
 };
@@ -703,6 +704,23 @@ static hipEvent_t so_prof_event() {
   hipEvent_t e = nullptr;
   (void)hipEventCreate(&e);
   return e;
+}
+
+int so_prof_begin(int key, double flops, int M, int N, int K, hipStream_t stream) {
+  if (!g_prof_on) return -1;
+  SoProfRec rec;
+  rec.e0 = so_prof_event();
+  rec.e1 = so_prof_event();
+  rec.key = key;
+  rec.flops = flops;
+  rec.M = M; rec.N = N; rec.K = K; rec.nclass = 1; rec.splitk = 1;
+  (void)hipEventRecord(rec.e0, stream);
+  g_prof.push_back(rec);
+  return (int)g_prof.size() - 1;
+}
+
+void so_prof_end(int slot, hipStream_t stream) {
+  if (slot >= 0 && slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
@@ -835,6 +853,8 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
 }
 
 static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// a forced tile / split-K (tests, tools) always means the general engine
+static bool so_forced() { return g_force_bm || g_force_splitk || g_force_nw; }
 
 // extent in bytes of a [rows][ld] fp32 operand; 0 -> too large for the 31-bit offsets used by the loaders
 static unsigned so_extent(long long rows, long long ld) {
@@ -932,6 +952,11 @@ int so_conv2d_fprop_padded(const float* x, int ldx, const float* w, const float*
                            int act, float act_param, float* ws, long long ws_bytes, void* stream) {
   if ((C & 3) || (ldx & 3) || !so_aligned16(x) || !so_aligned16(w)) return SO_ERR_ALIGN;
   if (Kw > Ko || Kw <= 0) return SO_ERR_SHAPE;
+  if (Ko == 4 && stride == 1 && !so_forced()) {  // four output channels: 4x4x1 MFMA kernel (thin.hip)
+    const int r = so_thin_conv(0, x, ldx, w, Kw, bias, Kw, y, ldy, Nb, H + 2 * pad - R + 1, W + 2 * pad - S + 1, H, W, C, R,
+                               S, pad, act, act_param, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = x; p.b = w; p.c = y; p.ws = ws; p.bias = bias; p.nbias = Kw;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
@@ -984,6 +1009,11 @@ int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int
                       long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || !so_aligned16(dy) || !so_aligned16(wt)) return SO_ERR_ALIGN;
   if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
+  if (C == 4 && stride == 1 && !so_forced()) {  // four input channels (RGB + pad): thin.hip
+    const int r = so_thin_conv(1, dy, lddy, wt, 4, nullptr, 0, dx, lddx, Nb, H, W, H + 2 * pad - R + 1, W + 2 * pad - S + 1,
+                               Ko, R, S, pad, SO_ACT_NONE, 0.f, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = dy; p.b = wt; p.c = dx; p.ws = ws;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
@@ -1006,6 +1036,11 @@ int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* d
                     long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || (C & 3) || (ldx & 3) || !so_aligned16(dy) || !so_aligned16(x))
     return SO_ERR_ALIGN;
+  if (Ko == 4 && stride == 1 && !so_forced()) {
+    const int r = so_thin_wgrad(dy, lddy, x, ldx, dw, 0, Nb, H, W, C, H + 2 * pad - R + 1, W + 2 * pad - S + 1, R, S, pad, ws,
+                                ws ? ws_bytes : 0, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = dy; p.b = x; p.c = dw; p.ws = ws;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
@@ -1027,6 +1062,11 @@ int so_conv2d_wgrad_acc(const float* dy, int lddy, const float* x, int ldx, floa
                         long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || (C & 3) || (ldx & 3) || !so_aligned16(dy) || !so_aligned16(x))
     return SO_ERR_ALIGN;
+  if (Ko == 4 && stride == 1 && !so_forced()) {
+    const int r = so_thin_wgrad(dy, lddy, x, ldx, dw, 1, Nb, H, W, C, H + 2 * pad - R + 1, W + 2 * pad - S + 1, R, S, pad, ws,
+                                ws ? ws_bytes : 0, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = dy; p.b = x; p.c = dw; p.ws = ws; p.res = dw;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;

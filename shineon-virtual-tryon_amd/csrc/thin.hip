@@ -1,0 +1,282 @@
+// Convolutions with FOUR channels on one side (gfx950).
+//
+// Three launches of a try-on step have a GEMM dimension of 4: the U-Net's last convolution (128 -> 4 channels at
+// full resolution; reference models/networks/cpvton/unet.py:146-152), its weight gradient, and the input gradient
+// of VGG conv1_1 (3 -> 64, RGB padded to 4; reference models/networks/vgg.py:6-36).  A 32x32 MFMA tile wastes 7/8
+// of its rows or columns on them.  v_mfma_f32_4x4x1_16B_f32 runs sixteen independent 4x4 outer products per
+// instruction at the full fp32 matrix rate, which fits exactly:
+//   conv / dgrad : block b = 4 pixels; A = the 4 weight rows (same for all blocks), B = one input value per
+//                  pixel  ->  lane l ends up with the 4 output channels of pixel l in its 4 accumulator registers
+//                  (one 16-byte store, no cross-lane shuffle).
+//   wgrad        : block b = 4 input channels; A = dy[pixel][0..3] (same for all blocks), B = x[pixel'][c]
+//                  ->  lane l accumulates dw[0..3][tap][c0 + l]; one coalesced 256-byte row of x feeds R*S MFMAs.
+// Register layout (checked on MI355X by tools/probes/mfma4x4.hip): D_b[i][j] is in lane 4b + j, register i;
+// A_b[i] is read from lane 4b + i, B_b[j] from lane 4b + j.
+#include "common.h"
+#include "thin.h"
+#include "../../include/shineon_hip.h"
+
+namespace {
+
+#define SO_OOB 0x80000000u
+typedef int so_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 thin_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  const so_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+  f32x4 r;
+  r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]);
+  r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
+  return r;
+}
+
+struct ThinConv {
+  const float* in;
+  const float* w;
+  const float* bias;
+  float* y;
+  unsigned in_bytes;
+  int ldin, ldy, OH, OW, IH, IW, IC, R, S, pad, M, K, wrows, nbias, act, vec_store;
+  float act_param;
+};
+
+// One thread per INPUT pixel of an 8 x 32 halo tile (a wave = two 32-pixel row segments).  Instead of gathering the
+// R*S taps per output pixel (which would re-read every input line R*S times through L1), each lane reads the IC
+// channels of its own pixel exactly once, in consecutive 16-byte quads (a 128-byte line is consumed by the lane
+// that fetched it), and accumulates z[tap][0..3] = sum_c x[pix][c] * w[j][tap][c] for ALL taps: R*S independent
+// MFMA chains per lane.  The output is the shifted sum out[a][b] = sum_tap z[(a,b) + tap][tap], exchanged through
+// LDS (pixel pitch 36 floats: conflict-free b128).  The (8-R+1) x (32-S+1) interior lanes of the tile own outputs.
+// Pixels outside the image read through the buffer descriptor at an out-of-range offset (zeros, branch-free).
+template <bool FLIP, int R, int S>
+__global__ __launch_bounds__(256) void thin_conv_k(const ThinConv p) {
+  constexpr int T = R * S, ZP = T * 4;  // z pitch: 36 floats for 3x3
+  constexpr int THo = 8 - (R - 1), TWo = 32 - (S - 1);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int KP = p.K + 4;
+  float* wl = smem;
+  float* zl = smem + 4 * KP;
+  const int kq = p.K >> 2;
+  for (int idx = tid; idx < 4 * kq; idx += 256) {
+    const int row = idx / kq, q = idx - row * kq;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < p.wrows) v = *reinterpret_cast<const f32x4*>(p.w + (long long)row * p.K + q * 4);
+    *reinterpret_cast<f32x4*>(wl + row * KP + q * 4) = v;
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const int tiles_w = (p.OW + TWo - 1) / TWo, tiles_h = (p.OH + THo - 1) / THo;
+  const int n = blockIdx.x / (tiles_h * tiles_w);
+  const int trem = blockIdx.x - n * (tiles_h * tiles_w);
+  const int th = trem / tiles_w, tw = trem - th * tiles_w;
+  const int oh0 = th * THo, ow0 = tw * TWo;
+  const int lr = tid >> 5, lc = tid & 31;
+  // input coordinates of this lane's halo pixel
+  const int ih = FLIP ? oh0 + p.pad - (R - 1) + lr : oh0 - p.pad + lr;
+  const int iw = FLIP ? ow0 + p.pad - (S - 1) + lc : ow0 - p.pad + lc;
+  const bool ok = ((unsigned)ih < (unsigned)p.IH) & ((unsigned)iw < (unsigned)p.IW);
+  const unsigned base = ok ? (unsigned)(((n * p.IH + ih) * p.IW + iw) * p.ldin) * 4u : SO_OOB;
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wrow = wl + (lane & 3) * KP;
+  const int Q = p.IC >> 2;
+#pragma unroll 2
+  for (int q = 0; q < Q; ++q) {
+    const f32x4 xv = thin_bload(rs, base + (unsigned)q * 16u);
+    f32x4 wv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wv[t] = *reinterpret_cast<const f32x4*>(wrow + t * p.IC + q * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[t][k], xv[k], acc[t], 0, 0, 0);
+  }
+
+  f32x4 v = acc[0];
+  if constexpr (T > 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(zl + tid * ZP + t * 4) = acc[t];
+    __syncthreads();
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (lr < THo && lc < TWo) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int dr = FLIP ? R - 1 - r : r, ds = FLIP ? S - 1 - s : s;
+          const f32x4 z = *reinterpret_cast<const f32x4*>(zl + ((lr + dr) * 32 + lc + ds) * ZP + (r * S + s) * 4);
+          v[0] += z[0]; v[1] += z[1]; v[2] += z[2]; v[3] += z[3];
+        }
+    }
+  }
+  const int oh = oh0 + lr, ow = ow0 + lc;
+  if (lr >= THo || lc >= TWo || oh >= p.OH || ow >= p.OW) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = v[i];
+    if (p.bias && i < p.nbias) a += p.bias[i];
+    v[i] = so_actf(p.act, a, p.act_param);
+  }
+  float* dst = p.y + ((long long)(n * p.OH + oh) * p.OW + ow) * p.ldy;
+  if (p.vec_store) {
+    *reinterpret_cast<f32x4*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = v[i];
+  }
+}
+
+struct ThinWgrad {
+  const float* dy;
+  const float* x;
+  float* ws;
+  int lddy, ldx, Nb, H, W, C, Ho, Wo, pad, rpb, cgb, LW;
+};
+
+// Block = `rpb` consecutive input rows (n, hi) x up to 256 channels.  The R dy rows a row of x pairs with are
+// staged (4 channels per pixel, zero halo) in LDS; wave w owns channel group w % cgb (64 channels, lane = channel)
+// and every (4 / cgb)-th pixel of the row.  Partial sums go to slab[blockIdx.x * subs + sub][4][R*S*C]; the slabs
+// are added in a fixed order by thin_reduce_k (deterministic, like the engine's split-K).
+template <int R, int S>
+__global__ __launch_bounds__(256) void thin_wgrad_k(const ThinWgrad p) {
+  extern __shared__ __attribute__((aligned(16))) float dyl[];  // [R][LW][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = wave % p.cgb, sub = wave / p.cgb, subs = 4 / p.cgb;
+  const int c0 = (blockIdx.y * p.cgb + cg) * 64;
+  f32x4 acc[R * S];
+#pragma unroll
+  for (int t = 0; t < R * S; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int rows = p.Nb * p.H;
+  for (int rr = 0; rr < p.rpb; ++rr) {
+    const int row = blockIdx.x * p.rpb + rr;
+    if (row >= rows) break;
+    const int n = row / p.H, hi = row - n * p.H;
+    __syncthreads();
+    for (int idx = tid; idx < R * p.LW; idx += 256) {
+      const int r = idx / p.LW, col = idx - r * p.LW;
+      const int ho = hi + p.pad - r, wo = col - (S - 1);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo)
+        v = *reinterpret_cast<const f32x4*>(p.dy + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.lddy);
+      *reinterpret_cast<f32x4*>(dyl + idx * 4) = v;
+    }
+    __syncthreads();
+    const float* xrow = p.x + (long long)(n * p.H + hi) * p.W * p.ldx + c0 + lane;
+    const float* dl = dyl + (lane & 3);
+    for (int wi0 = sub; wi0 < p.W; wi0 += 4 * subs) {
+      float xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int wi = wi0 + u * subs;
+        xv[u] = wi < p.W ? xrow[(long long)wi * p.ldx] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int wi = wi0 + u * subs;
+        const int wic = wi < p.W ? wi : 0;  // xv is 0 beyond the row; keep the LDS address in range
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const float a = dl[(r * p.LW + wic + p.pad - s + (S - 1)) * 4];
+            acc[r * S + s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, xv[u], acc[r * S + s], 0, 0, 0);
+          }
+      }
+    }
+  }
+  const long long E = 4LL * R * S * p.C;
+  float* slab = p.ws + (long long)(blockIdx.x * subs + sub) * E;
+#pragma unroll
+  for (int t = 0; t < R * S; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slab[((long long)i * R * S + t) * p.C + c0 + lane] = acc[t][i];
+}
+
+// out[e] = (accumulate ? out[e] : 0) + sum_slab ws[slab][e]; block = 64 elements x 16 slab groups.
+__global__ __launch_bounds__(1024) void thin_reduce_k(const float* ws, int nslab, long long E, float* out, int accumulate) {
+  __shared__ float part[16][64];
+  const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + ex;
+  float s = 0.f;
+  if (e < E)
+    for (int k = g; k < nslab; k += 16) s += ws[(long long)k * E + e];
+  part[g][ex] = s;
+  __syncthreads();
+  if (g == 0 && e < E) {
+    float t = accumulate ? out[e] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][ex];
+    out[e] = t;
+  }
+}
+
+}  // namespace
+
+int so_thin_conv(int flip, const float* in, int ldin, const float* w, int wrows, const float* bias, int nbias,
+                 float* y, int ldy, int Nb, int OH, int OW, int IH, int IW, int IC, int R, int S, int pad, int act,
+                 float act_param, hipStream_t stream) {
+  const long long K = (long long)R * S * IC;
+  const long long M = (long long)Nb * OH * OW;
+  const long long in_bytes = ((long long)Nb * IH * IW - 1) * ldin * 4 + (long long)IC * 4;
+  if (!((R == 3 && S == 3) || (R == 1 && S == 1)) || (IC & 3) || (ldin & 3) || K > 4092 || M <= 0 || M >= (1 << 30) || in_bytes >= 0x7fffffffLL || wrows < 1 || wrows > 4)
+    return 1;
+  ThinConv p = {};
+  p.in = in; p.w = w; p.bias = bias; p.y = y;
+  p.in_bytes = (unsigned)in_bytes;
+  p.ldin = ldin; p.ldy = ldy; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.R = R; p.S = S; p.pad = pad;
+  p.M = (int)M; p.K = (int)K; p.wrows = wrows; p.nbias = nbias; p.act = act; p.act_param = act_param;
+  p.vec_store = ((ldy & 3) == 0 && (((uintptr_t)y) & 15) == 0) ? 1 : 0;
+  const bool k3 = R == 3 && S == 3;
+  const int THo = k3 ? 6 : 8, TWo = k3 ? 30 : 32;
+  const size_t lds = ((size_t)4 * (K + 4) + (k3 ? 256 * 36 : 0)) * sizeof(float);
+  if (lds > 65536) return 1;
+  const int slot = so_prof_begin((flip ? 1 : 0) * 8 + 6, 2.0 * M * 4.0 * (double)K, (int)M, 4, (int)K, stream);
+  const dim3 grid((unsigned)((long long)Nb * so_cdiv(OH, THo) * so_cdiv(OW, TWo)));
+  if (k3) {
+    if (flip)
+      hipLaunchKernelGGL((thin_conv_k<true, 3, 3>), grid, dim3(256), lds, stream, p);
+    else
+      hipLaunchKernelGGL((thin_conv_k<false, 3, 3>), grid, dim3(256), lds, stream, p);
+  } else {
+    if (flip)
+      hipLaunchKernelGGL((thin_conv_k<true, 1, 1>), grid, dim3(256), lds, stream, p);
+    else
+      hipLaunchKernelGGL((thin_conv_k<false, 1, 1>), grid, dim3(256), lds, stream, p);
+  }
+  so_prof_end(slot, stream);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_thin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int accumulate, int Nb, int H, int W,
+                  int C, int Ho, int Wo, int R, int S, int pad, float* ws, long long ws_bytes, hipStream_t stream) {
+  if ((C & 63) || (lddy & 3) || !ws || !((R == 3 && S == 3) || (R == 1 && S == 1))) return 1;
+  const int cgb = C >= 256 ? 4 : C / 64;      // channel groups per block: 1, 2 or 4
+  if (cgb == 3 || C % (64 * cgb)) return 1;
+  const int subs = 4 / cgb;
+  const long long E = 4LL * R * S * C;
+  const int rows = Nb * H;
+  int rpb = rows / 512 > 0 ? rows / 512 : 1;  // aim for >= 512 blocks, then shrink the slab count to fit ws
+  while (rpb <= 64 && (long long)so_cdiv(rows, rpb) * subs * E * 4 > ws_bytes) rpb *= 2;
+  if (rpb > 64) return 1;
+  ThinWgrad p = {};
+  p.dy = dy; p.x = x; p.ws = ws;
+  p.lddy = lddy; p.ldx = ldx; p.Nb = Nb; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.pad = pad;
+  p.rpb = rpb; p.cgb = cgb; p.LW = W + pad + S;
+  const dim3 grid((unsigned)so_cdiv(rows, rpb), (unsigned)(C / (64 * cgb)));
+  const size_t lds = (size_t)R * p.LW * 4 * sizeof(float);
+  const long long Kpix = (long long)Nb * Ho * Wo;
+  const int slot = so_prof_begin(2 * 8 + 6, 2.0 * 4.0 * (double)(R * S * C) * (double)Kpix, 4, R * S * C, (int)Kpix, stream);
+  if (R == 3)
+    hipLaunchKernelGGL((thin_wgrad_k<3, 3>), grid, dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL((thin_wgrad_k<1, 1>), grid, dim3(256), lds, stream, p);
+  so_prof_end(slot, stream);
+  int err = SO_LAUNCH_CHECK();
+  if (err) return err;
+  hipLaunchKernelGGL(thin_reduce_k, dim3((unsigned)so_cdiv(E, 64)), dim3(1024), 0, stream, (const float*)ws,
+                     (int)(grid.x * subs), E, dw, accumulate);
+  return SO_LAUNCH_CHECK();
+}

@@ -61,6 +61,10 @@ CONV_CASES = [
     (2, 32, 9, 7, 16, 1, 1, 0),
     (2, 3, 16, 12, 64, 3, 1, 1),       # VGG conv1_1 shape class
     (4, 512, 4, 3, 512, 4, 2, 1),      # innermost U-Net level: tiny M, K = 8192
+    (2, 64, 16, 12, 4, 3, 1, 1),       # four output channels: 4x4x1-MFMA kernels (fprop + wgrad), U-Net last conv
+    (2, 128, 9, 7, 3, 3, 1, 1),        # three output channels padded to four, ragged pixel count
+    (2, 4, 16, 12, 64, 3, 1, 1),       # four input channels: 4x4x1-MFMA input gradient (VGG conv1_1 class)
+    (3, 64, 8, 6, 4, 1, 1, 0),         # 1x1 with four output channels
 ]
 
 
