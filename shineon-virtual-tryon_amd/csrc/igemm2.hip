@@ -187,11 +187,19 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   const int wm = wave / WGN, wn = wave % WGN;
 
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each
+  // with its own 4 MiB L2; handing XCD x the x-th CONTIGUOUS eighth of the (split, tile_m, tile_n) order keeps the
+  // activation rows (and their 3x3 halo) of neighbouring tiles in ONE L2 instead of all eight.  Any bijection is
+  // correct; this one only changes which L2 a tile's operands are fetched into.
+  const unsigned gx = gridDim.x, lin = blockIdx.x + gx * blockIdx.z, tot = gx * gridDim.z;
+  const unsigned xper = tot >> 3, xrem = tot & 7, xcd = lin & 7;
+  const unsigned lg = xcd * xper + (xcd < xrem ? xcd : xrem) + (lin >> 3);
+  const int bz = (int)(lg / gx), bx = (int)(lg - (unsigned)bz * gx);
+  const int tile_m = bx / tiles_n;
+  const int tile_n = bx - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int cls = blockIdx.z / p.splitk;
-  const int split = blockIdx.z - cls * p.splitk;
+  const int cls = bz / p.splitk;
+  const int split = bz - cls * p.splitk;
 
   const float* gA = p.a;
   const float* gB = p.b;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int n = n0 + wn * WTN + j * 32 + col4;
           if (m < p.M && n < p.N) {
             if (to_ws) {
-              *reinterpret_cast<f32x4*>(p.ws + ((long long)blockIdx.z * p.M + m) * p.N + n) = v;
+              *reinterpret_cast<f32x4*>(p.ws + ((long long)bz * p.M + m) * p.N + n) = v;
             } else {
               long long off, roff;
               so_row_offset<MODE>(p, cls, m, off, roff);
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       const int m = m0 + wm * WTM + i * 32 + row;
       if (m >= p.M) continue;
       if (to_ws) {
-        float* dst = p.ws + ((long long)blockIdx.z * p.M + m) * p.N;
+        float* dst = p.ws + ((long long)bz * p.M + m) * p.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn * WTN + j * 32 + li;

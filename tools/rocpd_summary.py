@@ -55,3 +55,28 @@ def main(db, prefix):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+
+
+def gaps(db, lo=0.4, hi=0.8):
+    """Idle time between kernels in the middle of the trace (steady-state graph replays): prints the busy
+    fraction, the number of gaps and the gap-length histogram."""
+    con = sqlite3.connect(db)
+    rows = con.execute("select start, end from rocpd_kernel_dispatch order by start").fetchall()
+    n = len(rows)
+    rows = rows[int(n * lo):int(n * hi)]
+    t0, busy_end, idle, hist = rows[0][0], rows[0][1], 0, {}
+    for s, e in rows[1:]:
+        if s > busy_end:
+            g = s - busy_end
+            idle += g
+            b = min(int(g / 1000), 20)
+            hist[b] = hist.get(b, 0) + 1
+        busy_end = max(busy_end, e)
+    span = busy_end - t0
+    print(f"window: {len(rows)} kernels, span {span / 1e6:.3f} ms, idle {idle / 1e6:.3f} ms ({100 * idle / span:.1f}%), "
+          f"mean gap {idle / max(1, sum(hist.values())) / 1e3:.2f} us")
+    print("gap histogram (us bucket: count):", dict(sorted(hist.items())))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "gaps":
+    gaps(sys.argv[1])
