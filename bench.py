@@ -252,6 +252,10 @@ def main():
                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
                    for k in range(32) if cnt[k] > 0}
         dom = max(range(32), key=lambda k: ms[k])
+        traffic = None  # HBM bytes per launch of the dominant instantiation, from the committed PMC passes
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(KEY_NAMES[dom], {}).get("hbm_bytes_per_launch")
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         mfma_ms = sum(ms) / prof_steps
         out = {
@@ -276,7 +280,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "timing": ("hip events, eager launches in the timed region" if args.no_graph else f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the graph-replayed timed region"), "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)" if traffic else None, "timing": ("hip events, eager launches in the timed region" if args.no_graph else f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the graph-replayed timed region"), "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
                 "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / (1e3 * elapsed / args.steps),
                 "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
             },

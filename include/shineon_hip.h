@@ -98,7 +98,7 @@ int so_igemm_plans_load(const char* path);
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
  * stream.  so_prof_collect waits for them and fills HOST arrays of 32 entries, key = mode*8 + tile
  * (mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm; tile 0 64x64, 1 128x64, 2 64x128, 3 128x128, 4 128x128/8 waves,
- * 5 64x128/8 waves): summed milliseconds, summed algorithmic FLOPs
+ * 5 64x128/8 waves, 6 the 4x4x1-MFMA kernels for four-channel convolutions): summed milliseconds, summed algorithmic FLOPs
  * (2*M*N*K per launch), launch count.  Returns the number of launches collected and clears the list. */
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
@@ -120,9 +120,10 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
                   const float* mean, const float* stat, int stat_is_var, float eps,
                   const float* gamma, const float* beta, void* stream);
 
+/* dgamma/dbeta (BatchNorm affine, optional): overwritten, or added to when accumulate != 0 (gradient slabs). */
 int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
                 long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                float* dgamma, float* dbeta, float* ws, void* stream);
+                float* dgamma, float* dbeta, int accumulate, float* ws, void* stream);
 
 /* ---- pointwise / resampling / reductions (csrc/elementwise.hip) ---------------------------------- */
 
@@ -212,9 +213,9 @@ int so_softmax_rows_fwd(const float* e, int lde, float* a, int lda, long long ro
 int so_softmax_rows_bwd(const float* a, int lda, const float* da, int ldda, float* de, int ldde,
                         long long rows, int ncol, void* stream);
 
-/* out[0] = scale * sum a*b (gradient of the attention gamma, sagan.py:53); ws >= 1024 floats */
+/* out[0] (+)= scale * sum a*b (gradient of the attention gamma, sagan.py:53); ws >= 1024 floats */
 int so_dot(const float* a, int lda, const float* b, int ldb, long long rows, int C, float scale,
-           float* out, float* ws, void* stream);
+           float* out, int accumulate, float* ws, void* stream);
 
 /* FeatureRegression.linear + tanh (warp.py:87,96-98): x NHWC [Nb][P][C] flattened in the reference's
  * (C, H, W) order, w [J][C*P], y [Nb][J]. */

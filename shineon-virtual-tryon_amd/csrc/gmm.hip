@@ -128,12 +128,12 @@ __global__ __launch_bounds__(256) void dot_partial_k(const float* __restrict__ a
 }
 
 __global__ __launch_bounds__(256) void sum_final_k(const float* __restrict__ part, unsigned n,
-                                                   float scale, float* __restrict__ out) {
+                                                   float scale, float* __restrict__ out, int accumulate) {
   __shared__ float red[4];
   float s = 0.f;
   for (unsigned i = threadIdx.x; i < n; i += 256) s += part[i];
   s = so_block_sum256(s, red);
-  if (threadIdx.x == 0) out[0] = scale * s;
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + scale * s;
 }
 
 // ------------------------------------------------------------------ regression head: Linear(C*P -> J) + tanh
@@ -533,13 +533,13 @@ int so_softmax_rows_bwd(const float* a, int lda, const float* da, int ldda, floa
 
 // ws: >= 1024 floats
 int so_dot(const float* a, int lda, const float* b, int ldb, long long rows, int C, float scale,
-           float* out, float* ws, void* stream) {
+           float* out, int accumulate, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int blocks = grid_for(rows * C);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(dot_partial_k, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
                      (unsigned)C, ws);
-  hipLaunchKernelGGL(sum_final_k, dim3(1), dim3(256), 0, st, ws, (unsigned)blocks, scale, out);
+  hipLaunchKernelGGL(sum_final_k, dim3(1), dim3(256), 0, st, ws, (unsigned)blocks, scale, out, accumulate);
   return SO_LAUNCH_CHECK();
 }
 

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict_
                                                         unsigned nchunk, unsigned C,
                                                         float* __restrict__ sums,
                                                         float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta) {
+                                                        float* __restrict__ dbeta, int accumulate) {
   __shared__ float sa[256], sb[256];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
@@ -202,7 +202,10 @@ __global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict_
   for (unsigned l = 0; l < 16; ++l) { a += sa[l * 16 + tx]; b += sb[l * 16 + tx]; }
   sums[(size_t)g * 2 * C + c] = a;
   sums[(size_t)g * 2 * C + C + c] = b;
-  if (dgamma) { dgamma[c] = b; dbeta[c] = a; }
+  if (dgamma) {
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + b;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + a;
+  }
 }
 
 // dx = rstd * gamma * (dy - s1/R - xhat * s2/R)
@@ -305,7 +308,7 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
 
 int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
                 long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                float* dgamma, float* dbeta, float* ws, void* stream) {
+                float* dgamma, float* dbeta, int accumulate, float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
   if (dgamma && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
@@ -319,7 +322,7 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
                      (unsigned)C, chunk, nchunk, mean, rstd, part);
   dim3 g2(so_cdiv(C, 16), G);
   hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(256), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
-                     dbeta);
+                     dbeta, accumulate);
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0)
     hipLaunchKernelGGL(norm_bwd_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,

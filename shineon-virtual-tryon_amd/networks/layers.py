@@ -78,10 +78,12 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._shared_counter = False  # True: the owner model bumps all counters with one launch (share_bn_counters)
 
     def forward(self, x):
         if self.training:
-            self.num_batches_tracked += 1
+            if not self._shared_counter:
+                self.num_batches_tracked += 1
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.momentum, self.eps)
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)
@@ -159,3 +161,17 @@ class HipUpsample2x(nn.Module):
 class HipMaxPool2x2(nn.Module):
     def forward(self, x):
         return ops.maxpool2x2(x)
+
+
+def share_bn_counters(model):
+    """Re-home every HipBatchNorm2d.num_batches_tracked of `model` as a view of ONE int64 tensor and return it, so a
+    training forward bumps all of them with a single `flat.add_(1)` instead of one tiny kernel per layer (14 in the
+    GMM).  state_dict keys / values are unchanged (load_state_dict copies into the views in place)."""
+    bns = [m for m in model.modules() if isinstance(m, HipBatchNorm2d)]
+    if not bns:
+        return None
+    flat = torch.stack([m.num_batches_tracked.reshape(()) for m in bns]).contiguous()
+    for i, m in enumerate(bns):
+        m._buffers["num_batches_tracked"] = flat[i]
+        m._shared_counter = True
+    return flat

@@ -517,6 +517,8 @@ class _NormFn(torch.autograd.Function):
         )
         ctx.save_for_backward(x, mean, rstd, gamma)
         ctx.cfg = (G, R)
+        # affine parameters living in the optimizer's flat slab get their gradients accumulated in place
+        ctx.direct = (gamma, beta) if gamma is not None and _direct_grad_ok(gamma, False) and _direct_grad_ok(beta, False) else None
         return y
 
     @staticmethod
@@ -528,16 +530,19 @@ class _NormFn(torch.autograd.Function):
         dy = to_rows(dy)
         dx = nhwc_empty(n, h, w, c, x.device)
         dgamma = dbeta = None
-        if gamma is not None:
+        gptr = bptr = None
+        if ctx.direct is not None:
+            gptr, bptr = ctx.direct[0].grad.data_ptr(), ctx.direct[1].grad.data_ptr()
+        elif gamma is not None:
             dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+            gptr, bptr = dgamma.data_ptr(), dbeta.data_ptr()
         ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
         check(
             L.so_norm_bwd(
                 x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
                 gamma.data_ptr() if gamma is not None else None,
-                dgamma.data_ptr() if dgamma is not None else None, dbeta.data_ptr() if dbeta is not None else None,
-                ws.data_ptr(), _stream(),
+                gptr, bptr, int(ctx.direct is not None), ws.data_ptr(), _stream(),
             ),
             "norm_bwd",
         )
@@ -617,6 +622,10 @@ class _SelfAttentionFn(torch.autograd.Function):
         check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
         ctx.save_for_backward(x, wq2, wk2, wv2, q, k, v, a, o, gamma)
         ctx.shapes = (tuple(wq.shape), tuple(wk.shape), tuple(wv.shape), d_true)
+        # parameters planted in the optimizer's flat slab: their gradients are accumulated in place by the kernels
+        params = (wq, bq, wk, bk, wv, bv, gamma)
+        ok = d == d_true and all(_direct_grad_ok(t, ohwi=t.dim() == 4) for t in params)
+        ctx.direct = params if ok else None
         return out
 
     @staticmethod
@@ -633,8 +642,10 @@ class _SelfAttentionFn(torch.autograd.Function):
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         ws = workspace(dev)
         # d gamma = <dout, o>
-        dgamma = f(1)
-        check(L.so_dot(gp, ldg, o.data_ptr(), c, b * n, c, 1.0, dgamma.data_ptr(), ws.data_ptr(), _stream()), "dot")
+        direct = ctx.direct
+        dgamma = f(1) if direct is None else None
+        check(L.so_dot(gp, ldg, o.data_ptr(), c, b * n, c, 1.0, (dgamma if direct is None else direct[6].grad).data_ptr(),
+                       int(direct is not None), ws.data_ptr(), _stream()), "dot")
         gm = gamma.data_ptr()
         # dv[b] = gamma * a[b]^T dout[b] ; da[b] = gamma * dout[b] v[b]^T
         dv = f(b * n, c)
@@ -655,6 +666,14 @@ class _SelfAttentionFn(torch.autograd.Function):
         _gemm(0, 0, b * n, c, c, dv.data_ptr(), c, 0, wv2.data_ptr(), c, 0, dxp, c, 0, 1, res=dxp, ldres=c, device=dev)
         # weight / bias gradients: dW = dY^T X
         xp, ldx = x.data_ptr(), _ld(x)
+        if direct is not None:
+            for g_, ldg_, rows_, wpar, bpar in ((dq, d, d, direct[0], direct[1]), (dk, d, d, direct[2], direct[3]),
+                                                (dv, c, c, direct[4], direct[5])):
+                wg = wpar.grad.data_ptr()
+                _gemm(1, 0, rows_, c, b * n, g_.data_ptr(), ldg_, 0, xp, ldx, 0, wg, c, 0, 1, res=wg, ldres=c, device=dev)
+                wsb = workspace(dev, L.so_colsum_ws_floats(b * n, rows_) * 4, lane=2)
+                check(L.so_colsum(g_.data_ptr(), ldg_, b * n, rows_, bpar.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
+            return dx, None, None, None, None, None, None, None
         dwq, dwk, dwv = f(d, c), f(d, c), f(c, c)
         _gemm(1, 0, d, c, b * n, dq.data_ptr(), d, 0, xp, ldx, 0, dwq.data_ptr(), c, 0, 1, device=dev)
         _gemm(1, 0, d, c, b * n, dk.data_ptr(), d, 0, xp, ldx, 0, dwk.data_ptr(), c, 0, 1, device=dev)
@@ -1052,7 +1071,7 @@ class _SumFn(torch.autograd.Function):
         out = torch.empty((), dtype=torch.float32, device=x.device)
         ws = workspace(x.device)
         check(lib().so_dot(xc.data_ptr(), xc.numel(), ones.data_ptr(), xc.numel(), 1, xc.numel(), 1.0, out.data_ptr(),
-                           ws.data_ptr(), _stream()), "dot")
+                           0, ws.data_ptr(), _stream()), "dot")
         ctx.shape = tuple(x.shape)
         return out
 

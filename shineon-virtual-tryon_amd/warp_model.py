@@ -12,6 +12,7 @@ from torch import nn
 from . import ops
 from .base_model import BaseModel
 from .io_png import get_save_paths, save_images
+from .networks.layers import HipBatchNorm2d, share_bn_counters
 from .networks.cpvton.warp import (FeatureCorrelation, FeatureExtraction, FeatureL2Norm, FeatureRegression,
                                    TpsGridGen)
 from .pl_compat import EvalResult, TrainResult
@@ -40,7 +41,20 @@ class WarpModel(BaseModel):
         self.regression = FeatureRegression(input_nc=192, output_dim=2 * hparams.grid_size ** 2)
         self.gridGen = TpsGridGen(hparams.fine_height, hparams.fine_width, grid_size=hparams.grid_size)
 
+    def _bump_bn_counters(self):
+        """num_batches_tracked += 1 for all 14 BatchNorm layers with one launch (layers.share_bn_counters)."""
+        flat = getattr(self, "_bn_flat", None)
+        first = next((m for m in self.modules() if isinstance(m, HipBatchNorm2d)), None)
+        if first is None:
+            return
+        if flat is None or first.num_batches_tracked.data_ptr() != flat.data_ptr():  # first use, or moved by .to()
+            flat = share_bn_counters(self)
+            object.__setattr__(self, "_bn_flat", flat)
+        flat.add_(1)
+
     def forward(self, inputA, inputB):
+        if self.training:
+            self._bump_bn_counters()
         featureA = self.extractionA(inputA)
         featureB = self.extractionB(inputB)
         featureA = self.l2norm(featureA, transpose_hw=True)  # the h<->w transpose of warp.py:60 is fused here

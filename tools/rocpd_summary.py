@@ -78,5 +78,33 @@ def gaps(db, lo=0.4, hi=0.8):
     print("gap histogram (us bucket: count):", dict(sorted(hist.items())))
 
 
+def exclusive(db, prefix, lo=0.4, hi=0.8):
+    """Wall-clock attribution: a kernel is charged only for the time by which it pushes the busy front forward
+    (end_i - max(start_i, latest end so far)), so the overlap between a draining kernel and its successor is not
+    counted twice.  Written as <prefix>_exclusive.csv over the middle (steady-state) part of the trace."""
+    con = sqlite3.connect(db)
+    rows = con.execute("""select d.start, d.end, s.kernel_name from rocpd_kernel_dispatch d
+                          join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
+    n = len(rows)
+    rows = rows[int(n * lo):int(n * hi)]
+    front = rows[0][0]
+    acc = {}
+    for s_, e_, name in rows:
+        ex = max(0, e_ - max(s_, front))
+        front = max(front, e_)
+        a = acc.setdefault(name, [0, 0, 0])
+        a[0] += 1
+        a[1] += ex
+        a[2] += e_ - s_
+    span = front - rows[0][0]
+    with open(prefix + "_exclusive.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "ExclusiveNs", "ExclusivePct", "InclusiveNs"])
+        for k, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, a[0], a[1], round(100.0 * a[1] / span, 3), a[2]])
+    print(f"exclusive attribution over {len(rows)} kernels, span {span / 1e6:.3f} ms -> {prefix}_exclusive.csv")
+
+
 if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "gaps":
     gaps(sys.argv[1])
+    exclusive(sys.argv[1], sys.argv[2])
