@@ -148,6 +148,12 @@ int so_upsample2x_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H,
                       void* stream);
 int so_upsample2x_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int H, int W, int C,
                       void* stream);
+/* the up path's `act -> Upsample` pair (unet.py:137-138,154-155,165-166) in one pass: y = upsample(act(x));
+ * backward dx = act'(x) * upsample^T(dy) (x = the activation's input) */
+int so_upsample2x_act_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, int act,
+                          float act_param, void* stream);
+int so_upsample2x_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb, int H,
+                          int W, int C, int act, float act_param, void* stream);
 
 /* MaxPool2d(2, 2) of VGG19 (vgg.py:9-23) */
 int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,

@@ -185,7 +185,8 @@ __device__ __forceinline__ void up_src(int o, int in, int& i0, int& i1, float& l
 template <int VEC>
 __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict__ x, int ldx,
                                                         float* __restrict__ y, int ldy, unsigned Nb,
-                                                        unsigned H, unsigned W, unsigned C) {
+                                                        unsigned H, unsigned W, unsigned C, int act,
+                                                        float act_param) {
   const unsigned CQ = C / VEC, Ho = 2 * H, Wo = 2 * W;
   const unsigned total = Nb * Ho * Wo * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -199,10 +200,17 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict_
     up_src((int)ho, (int)H, h0, h1, lh0, lh1);
     up_src((int)wo, (int)W, w0, w1, lw0, lw1);
     const float* base = x + (size_t)n * H * W * ldx + cq * VEC;
-    const Pack<VEC> a00 = ldp<VEC>(base + ((size_t)h0 * W + w0) * ldx);
-    const Pack<VEC> a01 = ldp<VEC>(base + ((size_t)h0 * W + w1) * ldx);
-    const Pack<VEC> a10 = ldp<VEC>(base + ((size_t)h1 * W + w0) * ldx);
-    const Pack<VEC> a11 = ldp<VEC>(base + ((size_t)h1 * W + w1) * ldx);
+    Pack<VEC> a00 = ldp<VEC>(base + ((size_t)h0 * W + w0) * ldx);
+    Pack<VEC> a01 = ldp<VEC>(base + ((size_t)h0 * W + w1) * ldx);
+    Pack<VEC> a10 = ldp<VEC>(base + ((size_t)h1 * W + w0) * ldx);
+    Pack<VEC> a11 = ldp<VEC>(base + ((size_t)h1 * W + w1) * ldx);
+    if (act != SO_ACT_NONE) {  // activation of the source pixels fused in front of the interpolation
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        a00.v[i] = so_actf(act, a00.v[i], act_param); a01.v[i] = so_actf(act, a01.v[i], act_param);
+        a10.v[i] = so_actf(act, a10.v[i], act_param); a11.v[i] = so_actf(act, a11.v[i], act_param);
+      }
+    }
     Pack<VEC> o;
 #pragma unroll
     for (int i = 0; i < VEC; ++i)
@@ -224,7 +232,8 @@ template <int VEC>
 __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict__ dy, int lddy,
                                                         float* __restrict__ dx, int lddx,
                                                         unsigned Nb, unsigned H, unsigned W,
-                                                        unsigned C) {
+                                                        unsigned C, const float* __restrict__ x, int ldx, int act,
+                                                        float act_param) {
   const unsigned CQ = C / VEC, Ho = 2 * H, Wo = 2 * W;
   const unsigned total = Nb * H * W * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -252,6 +261,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc.v[i] += wgt * g.v[i];
       }
+    }
+    if (act != SO_ACT_NONE) {  // chain rule through the activation fused in front of the upsample
+      const Pack<VEC> xv = ldp<VEC>(x + ((size_t)(n * H + hi) * W + wi) * ldx + cq * VEC);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc.v[i] *= so_actg(act, xv.v[i], act_param);
     }
     stp<VEC>(dx + ((size_t)(n * H + hi) * W + wi) * lddx + cq * VEC, acc);
   }
@@ -361,6 +375,24 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
   s = 0.f;
   for (unsigned l = 0; l < 16; ++l) s += sh[l * 16 + tx];
   out[c] = accumulate ? out[c] + s : s;
+}
+
+// One launch for short matrices (<= 4096 rows: attention projections, the 16x12 / 8x6 / 4x3 feature maps): a block of
+// 32 channels x 32 row-lanes, lanes merged in fixed order through LDS.
+__global__ __launch_bounds__(1024) void colsum_small_k(const float* __restrict__ x, int ldx, unsigned rows, unsigned C,
+                                                       float* __restrict__ out, int accumulate) {
+  __shared__ float sh[32][33];
+  const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const unsigned col = blockIdx.x * 32u + tx;
+  float s = 0.f;
+  if (col < C)
+    for (unsigned r = ty; r < rows; r += 32) s += x[(size_t)r * ldx + col];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty != 0 || col >= C) return;
+  s = 0.f;
+  for (unsigned l = 0; l < 32; ++l) s += sh[l][tx];
+  out[col] = accumulate ? out[col] + s : s;
 }
 
 // ------------------------------------------------------------------ L1 loss (mean |a-b|)
@@ -612,32 +644,43 @@ int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* st
   return SO_LAUNCH_CHECK();
 }
 
-int so_upsample2x_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
-                      void* stream) {
+int so_upsample2x_act_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, int act,
+                          float act_param, void* stream) {
   const long long total = (long long)Nb * H * W * 4 * C;
   if (total <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (VEC_OK2(x, ldx, y, ldy, C))
     hipLaunchKernelGGL(upsample2x_fwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y,
-                       ldy, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
+                       ldy, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param);
   else
     hipLaunchKernelGGL(upsample2x_fwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
+                       (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_upsample2x_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
+                      void* stream) {
+  return so_upsample2x_act_fwd(x, ldx, y, ldy, Nb, H, W, C, SO_ACT_NONE, 0.f, stream);
+}
+
+int so_upsample2x_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb, int H,
+                          int W, int C, int act, float act_param, void* stream) {
+  const long long total = (long long)Nb * H * W * C;
+  if (total <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool xok = act == SO_ACT_NONE || ((ldx & 3) == 0 && al16(x));
+  if (VEC_OK2(dy, lddy, dx, lddx, C) && xok)
+    hipLaunchKernelGGL(upsample2x_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, dy, lddy, dx,
+                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x, ldx, act, act_param);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, dx,
+                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x, ldx, act, act_param);
   return SO_LAUNCH_CHECK();
 }
 
 int so_upsample2x_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int H, int W, int C,
                       void* stream) {
-  const long long total = (long long)Nb * H * W * C;
-  if (total <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  if (VEC_OK2(dy, lddy, dx, lddx, C))
-    hipLaunchKernelGGL(upsample2x_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, dy, lddy, dx,
-                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
-  else
-    hipLaunchKernelGGL(upsample2x_bwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, dx,
-                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
-  return SO_LAUNCH_CHECK();
+  return so_upsample2x_act_bwd(nullptr, 0, dy, lddy, dx, lddx, Nb, H, W, C, SO_ACT_NONE, 0.f, stream);
 }
 
 int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
@@ -681,6 +724,11 @@ int so_colsum(const float* x, int ldx, long long rows, int C, float* out, int ac
               void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (rows <= 4096) {
+    hipLaunchKernelGGL(colsum_small_k, dim3(so_cdiv(C, 32)), dim3(1024), 0, st, x, ldx, (unsigned)rows, (unsigned)C, out,
+                       accumulate);
+    return SO_LAUNCH_CHECK();
+  }
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   const unsigned RL = 256 / CPB;
   const unsigned chunk = 64 * RL;

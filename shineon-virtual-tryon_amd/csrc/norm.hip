@@ -240,6 +240,117 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
 
 // inference BatchNorm backward is never needed on the hot path (test_step runs without grad).
 
+// ---- small statistics domains (R <= 1024 rows): everything in ONE launch ---------------------------------
+// Sixteen of the 26 norm layers of a try-on step normalise over at most 768 rows (U-Net levels below 32x24, the
+// 16x12 feature maps of the GMM and its regression head).  For those the three-kernel pipeline above is pure launch
+// latency, so one block of 1024 threads = 32 channels x 32 row-lanes owns a (group, 32-channel) panel: pass 1
+// accumulates shifted moments per thread, the row-lanes are merged in a fixed order through LDS (Chan), pass 2
+// re-reads the panel (L2-resident, <= 128 KiB) and writes the result.  Same formulas as the large path.
+__global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                         int ldy, unsigned R, unsigned C, float eps,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float momentum) {
+  __shared__ float sn[32][33], sm[32][33], s2[32][33];
+  __shared__ float bmean[32], brstd[32];
+  const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const unsigned col = blockIdx.x * 32u + tx, g = blockIdx.y;
+  const bool live = col < C;
+  const float* bx = x + (size_t)g * R * ldx + col;
+  float cnt = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
+  if (live) {
+    for (unsigned r = ty; r < R; r += 32) {
+      const float v = bx[(size_t)r * ldx];
+      if (cnt == 0.f) shift = v;
+      const float d = v - shift;
+      s += d;
+      ss += d * d;
+      cnt += 1.f;
+    }
+  }
+  float mu = 0.f, m2 = 0.f;
+  if (cnt > 0.f) {
+    mu = shift + s / cnt;
+    m2 = ss - s * s / cnt;
+    if (m2 < 0.f) m2 = 0.f;
+  }
+  sn[ty][tx] = cnt; sm[ty][tx] = mu; s2[ty][tx] = m2;
+  __syncthreads();
+  if (ty == 0 && live) {
+    Mom acc = {0.f, 0.f, 0.f};
+    for (unsigned l = 0; l < 32; ++l) acc = mom_merge(acc, Mom{sn[l][tx], sm[l][tx], s2[l][tx]});
+    const float var = acc.m2 / acc.n;
+    const float rs = 1.0f / sqrtf(var + eps);
+    mean[(size_t)g * C + col] = acc.mean;
+    rstd[(size_t)g * C + col] = rs;
+    bmean[tx] = acc.mean; brstd[tx] = rs;
+    if (running_mean) {
+      const float unbiased = acc.n > 1.f ? acc.m2 / (acc.n - 1.f) : var;
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * acc.mean;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float m = bmean[tx], rs = brstd[tx];
+  const float ga = gamma ? gamma[col] : 1.f, be = gamma ? beta[col] : 0.f;
+  float* by = y + (size_t)g * R * ldy + col;
+  for (unsigned r = ty; r < R; r += 32) {
+    float v = (bx[(size_t)r * ldx] - m) * rs;
+    if (gamma) v = v * ga + be;
+    by[(size_t)r * ldy] = v;
+  }
+}
+
+__global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict__ x, int ldx,
+                                                         const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                         int lddx, unsigned R, unsigned C,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate) {
+  __shared__ float p1[32][33], p2[32][33];
+  __shared__ float b1[32], b2[32];
+  const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const unsigned col = blockIdx.x * 32u + tx, g = blockIdx.y;
+  const bool live = col < C;
+  const float mu = live ? mean[(size_t)g * C + col] : 0.f, rs = live ? rstd[(size_t)g * C + col] : 0.f;
+  const float* bx = x + (size_t)g * R * ldx + col;
+  const float* bd = dy + (size_t)g * R * lddy + col;
+  float s1 = 0.f, s2 = 0.f;
+  if (live) {
+    for (unsigned r = ty; r < R; r += 32) {
+      const float d = bd[(size_t)r * lddy];
+      const float xh = (bx[(size_t)r * ldx] - mu) * rs;
+      s1 += d;
+      s2 += d * xh;
+    }
+  }
+  p1[ty][tx] = s1; p2[ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && live) {
+    float a = 0.f, b = 0.f;
+    for (unsigned l = 0; l < 32; ++l) { a += p1[l][tx]; b += p2[l][tx]; }
+    b1[tx] = a; b2[tx] = b;
+    if (dgamma) {
+      dgamma[col] = (accumulate ? dgamma[col] : 0.f) + b;
+      dbeta[col] = (accumulate ? dbeta[col] : 0.f) + a;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const float invR = 1.0f / (float)R;
+  const float a = b1[tx] * invR, b = b2[tx] * invR;
+  const float sc = gamma ? rs * gamma[col] : rs;
+  float* bo = dx + (size_t)g * R * lddx + col;
+  for (unsigned r = ty; r < R; r += 32) {
+    const float xh = (bx[(size_t)r * ldx] - mu) * rs;
+    bo[(size_t)r * lddx] = (bd[(size_t)r * lddy] - a - xh * b) * sc;
+  }
+}
+
+constexpr long long kSmallRows = 1024;
+
 inline int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -274,6 +385,11 @@ int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, 
   if (G <= 0 || R <= 0 || C <= 0) return 0;
   if (running_mean && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (R <= kSmallRows) {
+    hipLaunchKernelGGL(norm_small_fwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, y, ldy, (unsigned)R,
+                       (unsigned)C, eps, gamma, beta, mean, rstd, running_mean, running_var, momentum);
+    return SO_LAUNCH_CHECK();
+  }
   unsigned chunk, nchunk;
   chunking(R, C, chunk, nchunk);
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
@@ -312,6 +428,11 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
   if (G <= 0 || R <= 0 || C <= 0) return 0;
   if (dgamma && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  if (R <= kSmallRows) {
+    hipLaunchKernelGGL(norm_small_bwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, dy, lddy, dx, lddx,
+                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate);
+    return SO_LAUNCH_CHECK();
+  }
   unsigned chunk, nchunk;
   chunking(R, C, chunk, nchunk);
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;

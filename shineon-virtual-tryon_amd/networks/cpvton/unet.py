@@ -9,8 +9,8 @@ from torch import nn
 
 from ... import ops
 from ..attention.sagan import SelfAttention
-from ..layers import (HipConv2d, HipGELU, HipInstanceNorm2d, HipBatchNorm2d, HipLeakyReLU, HipReLU, HipUpsample2x,
-                      Sine, Swish)
+from ..layers import (HipActivation, HipConv2d, HipGELU, HipInstanceNorm2d, HipBatchNorm2d, HipLeakyReLU, HipReLU,
+                      HipUpsample2x, Sine, Swish)
 
 _NORMS = {"instance": HipInstanceNorm2d, "batch": HipBatchNorm2d}
 
@@ -98,15 +98,27 @@ class UnetSkipConnectionBlock(nn.Module):
 
     def forward(self, x):
         if self.outermost:
-            return self.model(x)
+            return _run(list(self.model), x)
         mods = list(self.model)
         if self.skip_carries_activation:
             x = mods[0](x)
             mods = mods[1:]
-        h = x
-        for m in mods:
+        return ops.cat_channels([x, _run(mods, x)])
+
+
+def _run(mods, h):
+    """nn.Sequential semantics with one fusion: an activation module directly followed by the bilinear upsample (the up
+    path's `act -> Upsample`) runs as a single kernel."""
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, HipActivation) and i + 1 < len(mods) and isinstance(mods[i + 1], HipUpsample2x):
+            h = ops.upsample2x_bilinear(h, m.kind, m.param)
+            i += 2
+        else:
             h = m(h)
-        return ops.cat_channels([x, h])
+            i += 1
+    return h
 
 
 def _get_activation_fn(activation):

@@ -442,26 +442,36 @@ def cat_channels(xs):
 
 
 class _Upsample2xFn(torch.autograd.Function):
+    """y = upsample2x(act(x)); act = ACT_NONE gives the plain nn.Upsample."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, act, param):
         x = to_rows(x)
         n, c, h, w = x.shape
         y = nhwc_empty(n, 2 * h, 2 * w, c, x.device)
-        check(lib().so_upsample2x_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, n, h, w, c, _stream()), "upsample2x_fwd")
+        check(lib().so_upsample2x_act_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, n, h, w, c, act, param, _stream()), "upsample2x_fwd")
         ctx.shape = (n, c, h, w)
+        ctx.cfg = (act, param)
+        if act != ACT_NONE:
+            ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         n, c, h, w = ctx.shape
+        act, param = ctx.cfg
         dy = to_rows(dy)
         dx = nhwc_empty(n, h, w, c, dy.device)
-        check(lib().so_upsample2x_bwd(dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, _stream()), "upsample2x_bwd")
-        return dx
+        x = ctx.saved_tensors[0] if act != ACT_NONE else None
+        check(lib().so_upsample2x_act_bwd(x.data_ptr() if x is not None else None, _ld(x) if x is not None else 0,
+                                          dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, act, param, _stream()), "upsample2x_bwd")
+        return dx, None, None
 
 
-def upsample2x_bilinear(x):
-    return _Upsample2xFn.apply(x)
+def upsample2x_bilinear(x, act=ACT_NONE, param=0.0):
+    """nn.Upsample(scale_factor=2, mode="bilinear"); with `act` the activation in front of it is applied in the same
+    pass (the U-Net up path's `act -> Upsample`, unet.py:137-138)."""
+    return _Upsample2xFn.apply(x, ACT_CODES[act] if not isinstance(act, int) else act, float(param))
 
 
 class _MaxPool2Fn(torch.autograd.Function):

@@ -151,8 +151,9 @@ def test_instance_norm_known_answer(ops, cuda):
     assert (yc.var(dim=(2, 3), unbiased=False) - 1).abs().max() < 1e-3
 
 
-def test_batch_norm_train_and_eval(ops, cuda):
-    x = rnd(4, 16, 8, 6, seed=14) * 1.5 + 0.5
+@pytest.mark.parametrize("hw", [(8, 6), (24, 16)])  # single-launch path (R <= 1024 rows) and the three-kernel path
+def test_batch_norm_train_and_eval(ops, cuda, hw):
+    x = rnd(4, 16, hw[0], hw[1], seed=14) * 1.5 + 0.5
     g, b = rnd(16, seed=15) * 0.1 + 1, rnd(16, seed=16) * 0.1
     rm, rv = torch.zeros(16), torch.ones(16)
     rm_g, rv_g = rm.clone().to(cuda), rv.clone().to(cuda)
@@ -164,6 +165,16 @@ def test_batch_norm_train_and_eval(ops, cuda):
     assert_close(rv_g, rv_c, atol=1e-6, what="running_var")
     y = ops.batch_norm_eval(x.to(cuda), g.to(cuda), b.to(cuda), rm_g, rv_g)
     assert_close(y, F.batch_norm(x, rm_c, rv_c, g, b, False, 0.1, 1e-5), atol=2e-5, what="batch_norm eval")
+
+
+@pytest.mark.parametrize("kind,ref", [("relu", F.relu), ("gelu", F.gelu), ("leaky", lambda t: F.leaky_relu(t, 0.2))])
+@pytest.mark.parametrize("c", [8, 6])
+def test_activation_fused_into_upsample(ops, cuda, kind, ref, c):
+    """The U-Net up path's `act -> Upsample(x2, bilinear)` pair as one kernel (forward and backward)."""
+    x = rnd(2, c, 6, 5, seed=18)
+    compare_fwd_bwd(lambda t: ops.upsample2x_bilinear(t, kind, 0.2 if kind == "leaky" else 0.0),
+                    lambda t: F.interpolate(ref(t), scale_factor=2, mode="bilinear", align_corners=False),
+                    [(x, True)], cuda, atol=2e-6, what=f"{kind}+upsample")
 
 
 def test_upsample_maxpool_cat(ops, cuda):
