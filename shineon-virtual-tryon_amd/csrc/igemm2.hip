@@ -63,6 +63,8 @@ struct SoIgemm {
   long long sa, sb, sc, sres;  // GEMM batch strides in elements
 };
 
+// pins memory ops (global, LDS) and MFMAs in source order; VALU/SALU address arithmetic may float across
+#define SO_SB() __builtin_amdgcn_sched_barrier(0x006)
 #define SO_OOB 0x80000000u  // byte offset beyond any operand (< 2 GiB each): buffer_load returns 0
 
 // floor(x / d) and x % d for 0 <= x < 2^24, d >= 1, with inv = 1.0f / d: one multiply + one correction step.
@@ -306,6 +308,21 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // WGRAD B: output pixel (n, ho, wo) of the thread's next k row, advanced incrementally (no per-quad division)
   int wg_n = 0, wg_ho = 0, wg_wo = 0, wg_dw = 0, wg_dh = 0, wg_dn = 0;
   (void)wg_n; (void)wg_ho; (void)wg_wo; (void)wg_dw; (void)wg_dh; (void)wg_dn;
+  // DGRAD with in-place weights (B_MC): (ko, ts, tr) of the thread's next k row
+  int dg_ko = 0, dg_ts = 0, dg_tr = 0, dg_dko = 0, dg_dts = 0, dg_dtr = 0;
+  (void)dg_ko; (void)dg_ts; (void)dg_tr; (void)dg_dko; (void)dg_dts; (void)dg_dtr;
+  if constexpr (MODE == MODE_DGRAD && B_MC) {
+    const int kk = kt_begin * BK + b_kr * BJ;
+    const int tapi = kk / p.Ko;
+    dg_ko = kk - tapi * p.Ko;
+    dg_tr = tapi / p.TS;
+    dg_ts = tapi - dg_tr * p.TS;
+    const int adv = BK - (BJ - 1);
+    const int q1 = adv / p.Ko;
+    dg_dko = adv - q1 * p.Ko;
+    dg_dtr = q1 / p.TS;
+    dg_dts = q1 - dg_dtr * p.TS;
+  }
   if constexpr (MODE == MODE_WGRAD) {
     const int kk = kt_begin * BK + b_kr * BJ;
     const int hw = p.Ho * p.Wo;
@@ -393,12 +410,27 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < BJ; ++j) {
         const int kk = k0 + b_kr * BJ + j;
         if constexpr (MODE == MODE_DGRAD) {
-          unsigned tapi, ko, tr, ts;
-          so_divmod((unsigned)kk, (unsigned)p.Ko, invKo, tapi, ko);
-          so_divmod(tapi, (unsigned)p.TS, invTS, tr, ts);
-          const int r = d_r0 + p.stride * (int)tr, s = d_s0 + p.stride * (int)ts;
+          // in-place OHWI weights: k row kk = (class tap (tr, ts), ko), carried incrementally like the WGRAD pixel
+          const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
-          rb[j] = so_bload(rB, ok ? (unsigned)(((int)ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+          rb[j] = so_bload(rB, ok ? (unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+          if (j + 1 < BJ) {
+            dg_ko += 1;
+            const bool c1 = dg_ko == p.Ko;
+            dg_ko = c1 ? 0 : dg_ko;
+            dg_ts += c1 ? 1 : 0;
+            const bool c2 = dg_ts == p.TS;
+            dg_ts = c2 ? 0 : dg_ts;
+            dg_tr += c2 ? 1 : 0;
+          } else {
+            dg_ko += dg_dko;
+            const bool c1 = dg_ko >= p.Ko;
+            dg_ko -= c1 ? p.Ko : 0;
+            dg_ts += dg_dts + (c1 ? 1 : 0);
+            const bool c2 = dg_ts >= p.TS;
+            dg_ts -= c2 ? p.TS : 0;
+            dg_tr += dg_dtr + (c2 ? 1 : 0);
+          }
         } else if constexpr (MODE == MODE_WGRAD) {
           // (wg_n, wg_ho, wg_wo) = output pixel of k row kk, carried from quad to quad and from tile to tile
           const int hi = wg_ho * p.stride - p.pad + w_r;
@@ -467,42 +499,40 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[0][r] = 0.f;
 
-  // multiply K-chunks [kc_lo, kc_hi) (8 k each) of LDS stage `st`
-  auto compute = [&](int st, int kc_lo, int kc_hi) {
+  // Fragments of one 8-k chunk (one ds_read_b128 per 32-row tile per operand) and the 4 MFMA steps they feed.
+  // Two fragment sets alternate so that the LDS reads of chunk c+1 are issued BEFORE the MFMAs of chunk c.
+  f32x4 fa[2][TM], fb[2][TN];
+  auto read_frag = [&](int st, int kc, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
     const float* as = As + st * A_STAGE;
     const float* bs = Bs + st * B_STAGE;
 #pragma unroll
-    for (int kc = kc_lo; kc < kc_hi; ++kc) {
-      float af[TM][4], bf[TN][4];
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WTM + i * 32 + li;
+      const int off = A_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+      af[i] = *reinterpret_cast<const f32x4*>(as + off);
+    }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * WTM + i * 32 + li;
-        const int off = A_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(as + off);
-        af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * WTN + j * 32 + li;
+      const int off = B_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+      bf[j] = *reinterpret_cast<const f32x4*>(bs + off);
+    }
+  };
+  auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+    if constexpr (KS == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; t += 2) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[0][t], acc[0][0], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t + 1], bf[0][t + 1], acc2[0], 0, 0, 0);
       }
+    } else {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * WTN + j * 32 + li;
-        const int off = B_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bs + off);
-        bf[j][0] = v[0]; bf[j][1] = v[1]; bf[j][2] = v[2]; bf[j][3] = v[3];
-      }
-      if constexpr (KS == 2) {
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; t += 2) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[0][t], acc[0][0], 0, 0, 0);
-          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t + 1], bf[0][t + 1], acc2[0], 0, 0, 0);
-        }
-      } else {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -521,20 +551,25 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // memory ops and MFMAs in this order while letting the address arithmetic (VALU/SALU) float between MFMAs.
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    compute(cur, 0, 1);
-    __builtin_amdgcn_sched_barrier(0x106);
+    read_frag(cur, 0, fa[0], fb[0]);
+    read_frag(cur, 1, fa[1], fb[1]);
+    SO_SB();
+    mma(fa[0], fb[0]);
+    SO_SB();
     store_a(cur ^ 1);   // tile kt+1, loaded during the previous iteration
-    __builtin_amdgcn_sched_barrier(0x106);
-    compute(cur, 1, 2);
-    __builtin_amdgcn_sched_barrier(0x106);
+    read_frag(cur, 2, fa[0], fb[0]);
+    SO_SB();
+    mma(fa[1], fb[1]);
+    SO_SB();
     store_b(cur ^ 1);
-    __builtin_amdgcn_sched_barrier(0x106);
-    compute(cur, 2, 3);
-    __builtin_amdgcn_sched_barrier(0x106);
+    read_frag(cur, 3, fa[1], fb[1]);
+    SO_SB();
+    mma(fa[0], fb[0]);
+    SO_SB();
     load_a(kt + 2);     // lands while tile kt+1 is multiplied
-    __builtin_amdgcn_sched_barrier(0x106);
-    compute(cur, 3, 4);
-    __builtin_amdgcn_sched_barrier(0x106);
+    SO_SB();
+    mma(fa[1], fb[1]);
+    SO_SB();
     load_b(kt + 2);
     __syncthreads();
     cur ^= 1;

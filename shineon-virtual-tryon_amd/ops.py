@@ -8,6 +8,7 @@ and a channel slice of a wider NHWC buffer when ld > C, so the reference's NCHW-
 interfaces are kept while the kernels see "pixel rows x channel columns".
 """
 import math
+import os
 import weakref
 
 import torch
@@ -53,6 +54,7 @@ _SIDE = {}
 # --steps 10): 289 frames/s with, 293 without — both GEMMs already fill the CUs, so sharing them only stretches
 # each kernel.  Off by default; kept as an experiment switch.
 CONCURRENT_WGRAD = False
+DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
 
 
 class _SideStream:
@@ -361,12 +363,21 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
-            wt = _ihwo(_pad_rows(w, op))  # transposed weights: both GEMM operands k-contiguous (same mode as fprop)
-            check(
-                L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op, r, s,
-                                    stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                "conv2d_dgrad_t",
-            )
+            if DGRAD_IN_PLACE:
+                # trainable weights change every step: read them in place (OHWI rows are contiguous along the GEMM
+                # column c; the engine transposes while staging) instead of writing a transposed copy per step
+                check(
+                    L.so_conv2d_dgrad(dy.data_ptr(), _ld(dy), _pad_rows(w, op).data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op,
+                                      r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                    "conv2d_dgrad",
+                )
+            else:
+                wt = _ihwo(_pad_rows(w, op))  # transposed weights: both GEMM operands k-contiguous (same mode as fprop)
+                check(
+                    L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op, r, s,
+                                        stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
+                    "conv2d_dgrad_t",
+                )
             dx = dxp if cp == i else dxp[:, :i]
         if fork is not None:
             fork.join()
