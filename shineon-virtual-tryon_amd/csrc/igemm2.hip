@@ -661,24 +661,56 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   }
 }
 
-// Sums the split-K slabs ws[cls][split][M][N] in split order (deterministic) and applies the epilogue.
-template <int MODE>
+// Sums the split-K slabs ws[cls][split][M][N] in a fixed order (deterministic) and applies the epilogue.  VEC = 4:
+// a thread owns four consecutive columns (16-byte loads / stores); eight slab loads are kept in flight per thread, the
+// kernel is otherwise one dependent-latency chain per split.
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) {
-  const long long total = (long long)p.nclass * p.M * p.N;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const long long mn = (long long)p.M * p.N;
+  const long long total = (long long)p.nclass * mn / VEC;
+  const int nq = p.N / VEC;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
-    const int cls = (int)(idx / mn);
-    const long long rem = idx - (long long)cls * mn;
-    const int m = (int)(rem / p.N);
-    const int n = (int)(rem - (long long)m * p.N);
-    const float* src = p.ws + (long long)cls * p.splitk * mn + rem;
-    float v = 0.f;
-    for (int s = 0; s < p.splitk; ++s) v += src[(long long)s * mn];
+    const int cls = (int)(idx / (mn / VEC));
+    const long long remq = idx - (long long)cls * (mn / VEC);
+    const int m = (int)(remq / nq);
+    const int n = (int)(remq - (long long)m * nq) * VEC;
+    const float* src = p.ws + (long long)cls * p.splitk * mn + (long long)m * p.N + n;
+    vec_t v = {};
+    int sidx = 0;
+    for (; sidx + 8 <= p.splitk; sidx += 8) {
+      vec_t t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const vec_t*>(src + (long long)(sidx + u) * mn);
+      v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    if (sidx + 4 <= p.splitk) {
+      vec_t t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec_t*>(src + (long long)(sidx + u) * mn);
+      v += (t[0] + t[1]) + (t[2] + t[3]);
+      sidx += 4;
+    }
+    for (; sidx < p.splitk; ++sidx) v += *reinterpret_cast<const vec_t*>(src + (long long)sidx * mn);
     long long off, roff;
     so_row_offset<MODE>(p, cls, m, off, roff);
     if (off < 0) continue;
-    p.c[off + n] = so_epilogue(p, v, roff, n);
+    if constexpr (VEC == 4) {
+      if (p.alpha) v *= p.alpha[0];
+      if (p.bias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (n + k < p.nbias) v[k] += p.bias[n + k];
+      }
+      if (p.res) v += *reinterpret_cast<const vec_t*>(p.res + roff + n);
+      if (p.act != SO_ACT_NONE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
+      }
+      *reinterpret_cast<vec_t*>(p.c + off + n) = v;
+    } else {
+      p.c[off + n] = so_epilogue(p, v[0], roff, n);
+    }
   }
 }
 
@@ -688,6 +720,8 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
 struct SoPlan {
   int bm, bn, splitk, ktps, nw;
 };
+
+static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Cost model: blocks are dealt round-robin to 256 CUs; a CU's time is (#blocks it owns) x (K tiles per block +
 // prologue/epilogue) x (tile FLOPs / per-CU MFMA rate) x a per-shape factor calibrated with tools/igemm_bench.py.
@@ -799,9 +833,15 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   if (err) return err;
   if (p.splitk > 1) {
     const long long total = (long long)p.nclass * p.M * p.N;
-    int blocks = so_cdiv(total, 256);
+    const bool wide = (p.N & 3) == 0 && (p.ldc & 3) == 0 && so_aligned16(p.c) && so_aligned16(p.ws) &&
+                      (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
+                      (!p.res || ((p.ldres & 3) == 0 && so_aligned16(p.res) && (MODE != MODE_GEMM || (p.sres & 3) == 0)));
+    int blocks = so_cdiv(wide ? total / 4 : total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(so_splitk_reduce_kernel<MODE>, dim3(blocks), dim3(256), 0, stream, p);
+    if (wide)
+      hipLaunchKernelGGL((so_splitk_reduce_kernel<MODE, 4>), dim3(blocks), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((so_splitk_reduce_kernel<MODE, 1>), dim3(blocks), dim3(256), 0, stream, p);
     err = SO_LAUNCH_CHECK();
   }
   return err;
@@ -902,7 +942,6 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   return so_launch_plan<MODE, A_MC, B_MC>(p, best, stream);
 }
 
-static bool so_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // a forced tile / split-K (tests, tools) always means the general engine
 static bool so_forced() { return g_force_bm || g_force_splitk || g_force_nw; }
 
