@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
   if (r1 > rows) r1 = rows;
   float s = 0.f;
   if (ty < RL && col < C)
+#pragma unroll 8
     for (unsigned r = r0 + ty; r < r1; r += RL) s += x[(size_t)r * ldx + col];
   red[threadIdx.x] = s;
   __syncthreads();
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ 
   const unsigned c = blockIdx.x * 16u + tx;
   float s = 0.f;
   if (c < C)
+#pragma unroll 8
     for (unsigned k = ty; k < nchunk; k += 16) s += part[(size_t)k * C + c];
   sh[threadIdx.x] = s;
   __syncthreads();
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(1024) void colsum_small_k(const float* __restrict__
   const unsigned col = blockIdx.x * 32u + tx;
   float s = 0.f;
   if (col < C)
+#pragma unroll 8
     for (unsigned r = ty; r < rows; r += 32) s += x[(size_t)r * ldx + col];
   sh[ty][tx] = s;
   __syncthreads();

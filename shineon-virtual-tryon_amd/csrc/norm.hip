@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void stats_partial_k(const float* __restrict__
   const float* base = x + (size_t)g * R * ldx;
   float cnt = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
   if (ty < RL && col < C) {
+#pragma unroll 8
     for (unsigned r = r0 + ty; r < r1; r += RL) {
       const float v = base[(size_t)r * ldx + col];
       if (cnt == 0.f) shift = v;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void stats_final_k(const float* __restrict__ p
   const unsigned g = blockIdx.y;
   Mom acc = {0.f, 0.f, 0.f};
   if (c < C) {
+#pragma unroll 8
     for (unsigned k = ty; k < nchunk; k += 16) {
       const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
       acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
@@ -161,6 +163,7 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restric
     const float mu = mean[(size_t)g * C + col], rs = rstd[(size_t)g * C + col];
     const float* bx = x + (size_t)g * R * ldx;
     const float* bd = dy + (size_t)g * R * lddy;
+#pragma unroll 8
     for (unsigned r = r0 + ty; r < r1; r += RL) {
       const float d = bd[(size_t)r * lddy + col];
       const float xh = (bx[(size_t)r * ldx + col] - mu) * rs;
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict_
   const unsigned g = blockIdx.y;
   float a = 0.f, b = 0.f;
   if (c < C) {
+#pragma unroll 8
     for (unsigned k = ty; k < nchunk; k += 16) {
       const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
       a += o[c]; b += o[C + c];
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
   const float* bx = x + (size_t)g * R * ldx + col;
   float cnt = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
   if (live) {
+#pragma unroll 8
     for (unsigned r = ty; r < R; r += 32) {
       const float v = bx[(size_t)r * ldx];
       if (cnt == 0.f) shift = v;
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
   const float m = bmean[tx], rs = brstd[tx];
   const float ga = gamma ? gamma[col] : 1.f, be = gamma ? beta[col] : 0.f;
   float* by = y + (size_t)g * R * ldy + col;
+#pragma unroll 8
   for (unsigned r = ty; r < R; r += 32) {
     float v = (bx[(size_t)r * ldx] - m) * rs;
     if (gamma) v = v * ga + be;
@@ -319,6 +325,7 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
   const float* bd = dy + (size_t)g * R * lddy + col;
   float s1 = 0.f, s2 = 0.f;
   if (live) {
+#pragma unroll 8
     for (unsigned r = ty; r < R; r += 32) {
       const float d = bd[(size_t)r * lddy];
       const float xh = (bx[(size_t)r * ldx] - mu) * rs;
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
   const float a = b1[tx] * invR, b = b2[tx] * invR;
   const float sc = gamma ? rs * gamma[col] : rs;
   float* bo = dx + (size_t)g * R * lddx + col;
+#pragma unroll 8
   for (unsigned r = ty; r < R; r += 32) {
     const float xh = (bx[(size_t)r * ldx] - mu) * rs;
     bo[(size_t)r * lddx] = (bd[(size_t)r * lddy] - a - xh * b) * sc;

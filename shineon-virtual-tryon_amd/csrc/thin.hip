@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void thin_conv_k(const ThinConv p) {
   for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wrow = wl + (lane & 3) * KP;
   const int Q = p.IC >> 2;
-#pragma unroll 2
   for (int q = 0; q < Q; ++q) {
     const f32x4 xv = thin_bload(rs, base + (unsigned)q * 16u);
     f32x4 wv[T];
@@ -201,8 +200,10 @@ __global__ __launch_bounds__(1024) void thin_reduce_k(const float* ws, int nslab
   const int ex = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long long e = (long long)blockIdx.x * 64 + ex;
   float s = 0.f;
-  if (e < E)
+  if (e < E) {
+#pragma unroll 8
     for (int k = g; k < nslab; k += 16) s += ws[(long long)k * E + e];
+  }
   part[g][ex] = s;
   __syncthreads();
   if (g == 0 && e < E) {
