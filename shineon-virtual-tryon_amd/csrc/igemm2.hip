@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 
   // Issue the (branch-free) global loads of K tile `kt` into ra/rb.  Tiles at or beyond kt_end read as zeros
   // without touching memory (every lane goes out of range), which lets the main loop run without tail branches.
-  auto load_a = [&](int kt) {
+  auto load_a = [&](int kt, f32x4 (&dst)[AJ]) {
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!A_MC) {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int hi = a_h0[j] + (int)r, wi = a_w0[j] + (int)s;
           const bool ok = kvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
         }
       } else if constexpr (MODE == MODE_DGRAD) {
         unsigned tapi, ko, tr, ts;
@@ -365,13 +365,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int ho = a_h0[j] - (int)tr, wo = a_w0[j] - (int)ts;
           const bool ok = kvalid & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
-          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
           const bool ok = kvalid & (a_h0[j] == 0);
-          ra[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + (int)kk) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + (int)kk) * 4u : SO_OOB);
         }
       }
     } else {
@@ -381,11 +381,11 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j) {
         const int kk = k0 + a_kr * AJ + j;
         const bool ok = colok & (kk < Klim);
-        ra[j] = so_bload(rA, ok ? (unsigned)(kk * p.lda + col) * 4u : SO_OOB);
+        dst[j] = so_bload(rA, ok ? (unsigned)(kk * p.lda + col) * 4u : SO_OOB);
       }
     }
   };
-  auto load_b = [&](int kt) {
+  auto load_b = [&](int kt, f32x4 (&dst)[BJ]) {
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!B_MC) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const bool ok = kvalid & (b_row[j] >= 0);
-        rb[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + koff) * 4u : SO_OOB);
+        dst[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + koff) * 4u : SO_OOB);
       }
     } else {
       const int col = n0 + b_mq * 4;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           // in-place OHWI weights: k row kk = (class tap (tr, ts), ko), carried incrementally like the WGRAD pixel
           const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
-          rb[j] = so_bload(rB, ok ? (unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, ok ? (unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
           if (j + 1 < BJ) {
             dg_ko += 1;
             const bool c1 = dg_ko == p.Ko;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int hi = wg_ho * p.stride - p.pad + w_r;
           const int wi = wg_wo * p.stride - p.pad + w_s;
           const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          rb[j] = so_bload(rB, ok ? (unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, ok ? (unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
           if (j + 1 < BJ) {  // next k row = next output pixel
             wg_wo += 1;
             const bool cw = wg_wo == p.Wo;
@@ -456,30 +456,30 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           }
         } else {
           const bool ok = (kk < Klim) & (col < p.N);
-          rb[j] = so_bload(rB, ok ? (unsigned)(kk * p.ldb + col) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, ok ? (unsigned)(kk * p.ldb + col) * 4u : SO_OOB);
         }
       }
     }
   };
 
-  auto store_a = [&](int st) {
+  auto store_a = [&](int st, const f32x4 (&src)[AJ]) {
     float* as = As + st * A_STAGE;
     if constexpr (!A_MC) {
 #pragma unroll
       for (int j = 0; j < AJ; ++j)
-        *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = ra[j];
+        *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
     } else {
-      so_store_transposed<AJ>(as, a_st, ra);
+      so_store_transposed<AJ>(as, a_st, src);
     }
   };
-  auto store_b = [&](int st) {
+  auto store_b = [&](int st, const f32x4 (&src)[BJ]) {
     float* bs = Bs + st * B_STAGE;
     if constexpr (!B_MC) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j)
-        *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = rb[j];
+        *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
     } else {
-      so_store_transposed<BJ>(bs, b_st, rb);
+      so_store_transposed<BJ>(bs, b_st, src);
     }
   };
 
@@ -536,13 +536,17 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     }
   };
 
-  // prologue: tile 0 -> LDS[0]; tile 1 in flight in registers
-  load_a(kt_begin);
-  load_b(kt_begin);
-  store_a(0);
-  store_b(0);
-  load_a(kt_begin + 1);
-  load_b(kt_begin + 1);
+  // prologue: the loads of tiles 0 and 1 are issued back to back (one exposed memory latency instead of two),
+  // tile 0 -> LDS[0]; tile 1 stays in flight in registers
+  {
+    f32x4 ra0[AJ], rb0[BJ];
+    load_a(kt_begin, ra0);
+    load_b(kt_begin, rb0);
+    load_a(kt_begin + 1, ra);
+    load_b(kt_begin + 1, rb);
+    store_a(0, ra0);
+    store_b(0, rb0);
+  }
   __syncthreads();
 
   // main loop: one straight-line block per K tile (past-the-end tiles load zeros for free, see load_a).
@@ -556,21 +560,21 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     SO_SB();
     mma(fa[0], fb[0]);
     SO_SB();
-    store_a(cur ^ 1);   // tile kt+1, loaded during the previous iteration
+    store_a(cur ^ 1, ra);   // tile kt+1, loaded during the previous iteration
     read_frag(cur, 2, fa[0], fb[0]);
     SO_SB();
     mma(fa[1], fb[1]);
     SO_SB();
-    store_b(cur ^ 1);
+    store_b(cur ^ 1, rb);
     read_frag(cur, 3, fa[1], fb[1]);
     SO_SB();
     mma(fa[0], fb[0]);
     SO_SB();
-    load_a(kt + 2);     // lands while tile kt+1 is multiplied
+    load_a(kt + 2, ra);     // lands while tile kt+1 is multiplied
     SO_SB();
     mma(fa[1], fb[1]);
     SO_SB();
-    load_b(kt + 2);
+    load_b(kt + 2, rb);
     __syncthreads();
     cur ^= 1;
   }
