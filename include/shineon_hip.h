@@ -58,6 +58,12 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
 int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int lddx, int Nb, int H,
                       int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                       long long ws_bytes, void* stream);
+/* so_conv2d_dgrad_t with the backward of the ReLU that produced the convolution's input fused into the epilogue:
+ * dx[p][c] = gate[p][c] > 0 ? dx[p][c] : 0, `gate` = that ReLU's output ([Nb*H*W][C], pitch lddx).  Used by the frozen
+ * VGG19 chain of the perceptual loss (loss.py:106-122), where conv -> ReLU -> conv repeats 13 times. */
+int so_conv2d_dgrad_t_gated(const float* dy, int lddy, const float* wt, float* dx, int lddx, const float* gate,
+                            int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                            long long ws_bytes, void* stream);
 /* w[ko][tap][c] (OHWI) -> wt[c][tap][ko] (IHWO) */
 int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* stream);
 
@@ -158,8 +164,9 @@ int so_upsample2x_act_bwd(const float* x, int ldx, const float* dy, int lddy, fl
 /* MaxPool2d(2, 2) of VGG19 (vgg.py:9-23) */
 int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
                     void* stream);
+/* relu_gate != 0: x is a ReLU output; the gradient is also chained through that ReLU (zero where the window max is 0) */
 int so_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb,
-                    int H, int W, int C, void* stream);
+                    int H, int W, int C, int relu_gate, void* stream);
 
 /* bias gradient: out[c] (+)= sum_rows x[row][c] */
 long long so_colsum_ws_floats(long long rows, int C);
@@ -168,11 +175,12 @@ int so_colsum(const float* x, int ldx, long long rows, int C, float* out, int ac
 
 /* F.l1_loss / nn.L1Loss (warp_model.py:88; unet_mask_model.py:174-184; loss.py:110,121):
  * out[0] (+)= scale * sum |a - b| (scale = weight / numel); ws >= 1024 floats.
- * backward: da (+)= sign(a - b) * gout[0] * scale. */
+ * backward: da (+)= sign(a - b) * gout[0] * scale; relu_gate != 0: `a` is a ReLU output and da is the gradient in
+ * front of that ReLU (zero where a == 0). */
 int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long rows, int C,
                    float scale, float* out, int accumulate, float* ws, void* stream);
 int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
-                   float* da, int ldda, long long rows, int C, int accumulate, void* stream);
+                   float* da, int ldda, long long rows, int C, int accumulate, int relu_gate, void* stream);
 
 /* tanh / sigmoid / mask blend of UnetMaskModel.forward (unet_mask_model.py:84-86,126-129), one frame:
  * o: [pix][>=4] network output; cloth: [pix][>=3]; outputs rendered [pix][3], mask [pix][1],

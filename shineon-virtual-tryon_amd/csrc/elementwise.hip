@@ -299,7 +299,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void maxpool2_bwd_k(const float* __restrict__ x, int ldx,
                                                       const float* __restrict__ dy, int lddy,
                                                       float* __restrict__ dx, int lddx, unsigned Nb,
-                                                      unsigned H, unsigned W, unsigned C) {
+                                                      unsigned H, unsigned W, unsigned C, int relu_gate) {
   const unsigned CQ = C / VEC, Ho = H / 2, Wo = W / 2;
   const unsigned total = Nb * Ho * Wo * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_k(const float* __restrict__ 
     const float* base = x + p00 * ldx + cq * VEC;
     const Pack<VEC> a = ldp<VEC>(base), b = ldp<VEC>(base + ldx);
     const Pack<VEC> c = ldp<VEC>(base + (size_t)W * ldx), d = ldp<VEC>(base + (size_t)(W + 1) * ldx);
-    const Pack<VEC> g = ldp<VEC>(dy + ((size_t)(n * Ho + ho) * Wo + wo) * lddy + cq * VEC);
+    Pack<VEC> g = ldp<VEC>(dy + ((size_t)(n * Ho + ho) * Wo + wo) * lddy + cq * VEC);
     Pack<VEC> ga, gb, gc, gd;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_k(const float* __restrict__ 
       if (b.v[i] > m) { m = b.v[i]; arg = 1; }
       if (c.v[i] > m) { m = c.v[i]; arg = 2; }
       if (d.v[i] > m) { m = d.v[i]; arg = 3; }
+      if (relu_gate && !(m > 0.f)) g.v[i] = 0.f;  // x is a ReLU output: the window's maximum gates the gradient
       ga.v[i] = arg == 0 ? g.v[i] : 0.f;
       gb.v[i] = arg == 1 ? g.v[i] : 0.f;
       gc.v[i] = arg == 2 ? g.v[i] : 0.f;
@@ -430,13 +431,15 @@ __global__ __launch_bounds__(256) void l1_bwd_k(const float* __restrict__ a, int
                                                 const float* __restrict__ b, int ldb,
                                                 const float* __restrict__ gout, float scale,
                                                 float* __restrict__ da, int ldda, unsigned rows,
-                                                unsigned C, int accumulate) {
+                                                unsigned C, int accumulate, int relu_gate) {
   const unsigned total = rows * C;
   const float g = gout[0] * scale;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / C, c = idx - row * C;
-    const float d = a[(size_t)row * lda + c] - b[(size_t)row * ldb + c];
-    const float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    const float av = a[(size_t)row * lda + c];
+    const float d = av - b[(size_t)row * ldb + c];
+    float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+    if (relu_gate && !(av > 0.f)) v = 0.f;  // `a` is a ReLU output: chain through the ReLU in the same pass
     float* o = da + (size_t)row * ldda + c;
     *o = accumulate ? *o + v : v;
   }
@@ -702,17 +705,17 @@ int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, i
 }
 
 int so_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb,
-                    int H, int W, int C, void* stream) {
+                    int H, int W, int C, int relu_gate, void* stream) {
   if ((H & 1) || (W & 1)) return SO_ERR_SHAPE;
   const long long total = (long long)Nb * (H / 2) * (W / 2) * C;
   if (total <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (VEC_OK2(x, ldx, dy, lddy, C) && (lddx & 3) == 0 && al16(dx))
     hipLaunchKernelGGL(maxpool2_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,
-                       lddy, dx, lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
+                       lddy, dx, lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, relu_gate);
   else
     hipLaunchKernelGGL(maxpool2_bwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, dy, lddy,
-                       dx, lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C);
+                       dx, lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, relu_gate);
   return SO_LAUNCH_CHECK();
 }
 
@@ -758,10 +761,10 @@ int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long r
 }
 
 int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
-                   float* da, int ldda, long long rows, int C, int accumulate, void* stream) {
+                   float* da, int ldda, long long rows, int C, int accumulate, int relu_gate, void* stream) {
   if (rows * C <= 0) return 0;
   hipLaunchKernelGGL(l1_bwd_k, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
-                     ldb, gout, scale, da, ldda, (unsigned)rows, (unsigned)C, accumulate);
+                     ldb, gout, scale, da, ldda, (unsigned)rows, (unsigned)C, accumulate, relu_gate);
   return SO_LAUNCH_CHECK();
 }
 

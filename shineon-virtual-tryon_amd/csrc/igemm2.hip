@@ -48,6 +48,7 @@ struct SoIgemm {
   const float* bias;
   const float* alpha;
   const float* res;
+  const float* gate;  // optional ReLU gate (same pitch as c): out = gate > 0 ? out : 0, applied last
   unsigned a_bytes, b_bytes;  // buffer extents for the descriptors (per batch matrix in GEMM mode)
   int M, N, K;
   int lda, ldb, ldc, ldres;
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   const bool wide = (p.N & 3) == 0 &&
                     (to_ws || ((p.ldc & 3) == 0 && (((uintptr_t)p.c) & 15) == 0 && (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
                                (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0 &&
-                                           (MODE != MODE_GEMM || (p.sres & 3) == 0)))));
+                                           (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
+                               (!p.gate || (((uintptr_t)p.gate) & 15) == 0)));
   if (wide) {
     float* stg = smem + wave * (32 * LDK);
 #pragma unroll
@@ -627,6 +629,11 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
                   for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
                 }
+                if (p.gate) {
+                  const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + off + n);
+#pragma unroll
+                  for (int k = 0; k < 4; ++k) v[k] = gv[k] > 0.f ? v[k] : 0.f;
+                }
                 *reinterpret_cast<f32x4*>(p.c + off + n) = v;
               }
             }
@@ -658,7 +665,10 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn * WTN + j * 32 + li;
-          if (n < p.N) p.c[off + n] = so_epilogue(p, acc[i][j][r], roff, n);
+          if (n < p.N) {
+            const float e = so_epilogue(p, acc[i][j][r], roff, n);
+            p.c[off + n] = (!p.gate || p.gate[off + n] > 0.f) ? e : 0.f;
+          }
         }
       }
     }
@@ -711,9 +721,15 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
       }
+      if (p.gate) {
+        const vec_t gv = *reinterpret_cast<const vec_t*>(p.gate + off + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = gv[k] > 0.f ? v[k] : 0.f;
+      }
       *reinterpret_cast<vec_t*>(p.c + off + n) = v;
     } else {
-      p.c[off + n] = so_epilogue(p, v[0], roff, n);
+      const float e = so_epilogue(p, v[0], roff, n);
+      p.c[off + n] = (!p.gate || p.gate[off + n] > 0.f) ? e : 0.f;
     }
   }
 }
@@ -839,7 +855,8 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
     const long long total = (long long)p.nclass * p.M * p.N;
     const bool wide = (p.N & 3) == 0 && (p.ldc & 3) == 0 && so_aligned16(p.c) && so_aligned16(p.ws) &&
                       (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
-                      (!p.res || ((p.ldres & 3) == 0 && so_aligned16(p.res) && (MODE != MODE_GEMM || (p.sres & 3) == 0)));
+                      (!p.res || ((p.ldres & 3) == 0 && so_aligned16(p.res) && (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
+                      (!p.gate || so_aligned16(p.gate));
     int blocks = so_cdiv(wide ? total / 4 : total, 256);
     if (blocks > 4096) blocks = 4096;
     if (wide)
@@ -1097,18 +1114,18 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
 
 // Input gradient with TRANSPOSED weights wt[c][r][s][ko] (so_ohwi_to_ihwo): both operands are k-contiguous, the
 // kernel runs in the same KC x KC mode as the forward convolution (ds_read_b128 fragments on both sides).
-int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int lddx, int Nb, int H,
-                      int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
-                      long long ws_bytes, void* stream) {
+int so_conv2d_dgrad_t_gated(const float* dy, int lddy, const float* wt, float* dx, int lddx, const float* gate,
+                            int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                            long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || !so_aligned16(dy) || !so_aligned16(wt)) return SO_ERR_ALIGN;
   if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
-  if (C == 4 && stride == 1 && !so_forced()) {  // four input channels (RGB + pad): thin.hip
+  if (C == 4 && stride == 1 && !so_forced() && !gate) {  // four input channels (RGB + pad): thin.hip
     const int r = so_thin_conv(1, dy, lddy, wt, 4, nullptr, 0, dx, lddx, Nb, H, W, H + 2 * pad - R + 1, W + 2 * pad - S + 1,
                                Ko, R, S, pad, SO_ACT_NONE, 0.f, (hipStream_t)stream);
     if (r != 1) return r;
   }
   SoIgemm p = {};
-  p.a = dy; p.b = wt; p.c = dx; p.ws = ws;
+  p.a = dy; p.b = wt; p.c = dx; p.ws = ws; p.gate = gate;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
   p.Ho = (H + 2 * pad - R) / stride + 1;
   p.Wo = (W + 2 * pad - S) / stride + 1;
@@ -1122,6 +1139,12 @@ int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int
   if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = SO_ACT_NONE;
   return so_launch<MODE_DGRAD, false, false>(p, ws_bytes, (hipStream_t)stream);
+}
+
+int so_conv2d_dgrad_t(const float* dy, int lddy, const float* wt, float* dx, int lddx, int Nb, int H,
+                      int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
+                      long long ws_bytes, void* stream) {
+  return so_conv2d_dgrad_t_gated(dy, lddy, wt, dx, lddx, nullptr, Nb, H, W, C, Ko, R, S, stride, pad, ws, ws_bytes, stream);
 }
 
 int so_conv2d_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int Nb, int H,

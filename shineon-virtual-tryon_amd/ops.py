@@ -501,7 +501,7 @@ class _MaxPool2Fn(torch.autograd.Function):
         n, c, h, w = x.shape
         dy = to_rows(dy)
         dx = nhwc_empty(n, h, w, c, x.device)
-        check(lib().so_maxpool2_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, _stream()), "maxpool2_bwd")
+        check(lib().so_maxpool2_bwd(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, n, h, w, c, 0, _stream()), "maxpool2_bwd")
         return dx
 
 
@@ -973,7 +973,7 @@ class _L1LossFn(torch.autograd.Function):
             da = nhwc_empty(n, h, w, ch, a2.device)
         else:
             da = torch.empty(shape, dtype=torch.float32, device=a2.device)
-        check(lib().so_l1_loss_bwd(a2.data_ptr(), lda, b2.data_ptr(), ldb, gout.data_ptr(), scale, da.data_ptr(), c, rows, c, 0, _stream()), "l1_bwd")
+        check(lib().so_l1_loss_bwd(a2.data_ptr(), lda, b2.data_ptr(), ldb, gout.data_ptr(), scale, da.data_ptr(), c, rows, c, 0, 0, _stream()), "l1_bwd")
         return da, None, None
 
 
@@ -1143,13 +1143,15 @@ class _VggLossFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         fill_(loss, 0.0)
         cur, saved, meta, pi = inp, [], [], 0
+        relu_in = None  # index in `saved` of the ReLU output that is the current tensor (None: image / pooled map)
         for item in cfg:
             n2, ci, hh, ww = cur.shape
             if item[0] == "M":
                 out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
                 check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
                 saved.append(cur)
-                meta.append(("M", len(saved) - 1))
+                meta.append(("M", len(saved) - 1, relu_in is not None))
+                relu_in = None
             else:
                 weight, bias = params[pi], params[pi + 1]
                 pi += 2
@@ -1164,7 +1166,8 @@ class _VggLossFn(torch.autograd.Function):
                     check(L.so_l1_loss_fwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, rows, co, tap_w / (rows * co),
                                            loss.data_ptr(), 1, ws.data_ptr(), _stream()), "l1_fwd")
                 saved.extend([out, wk])
-                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci, (weakref.ref(weight), weight._version)))
+                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci, (weakref.ref(weight), weight._version), relu_in))
+                relu_in = len(saved) - 2
             cur = out
         ctx.save_for_backward(*saved)
         ctx.meta = (meta, b, c, cp)
@@ -1178,16 +1181,18 @@ class _VggLossFn(torch.autograd.Function):
         dev = gout.device
         gout = gout.contiguous()
         ws = workspace(dev)
+        # `g` is always the gradient IN FRONT of the current layer's ReLU: every producer applies that ReLU's mask itself
+        # (dgrad epilogue gate, max-pool backward gate, L1 backward gate), so no separate mask pass runs.
         g = None
         for m in reversed(meta):
             if m[0] == "M":
                 xin = saved[m[1]]
                 _, ci, hh, ww = xin.shape
                 dx = nhwc_empty(b, hh, ww, ci, dev)
-                check(L.so_maxpool2_bwd(xin.data_ptr(), ci, g.data_ptr(), ci, dx.data_ptr(), ci, b, hh, ww, ci, _stream()), "maxpool2_bwd")
+                check(L.so_maxpool2_bwd(xin.data_ptr(), ci, g.data_ptr(), ci, dx.data_ptr(), ci, b, hh, ww, ci, int(m[2]), _stream()), "maxpool2_bwd")
                 g = dx
                 continue
-            _, oi, wi, tap_w, ci, wkey = m
+            _, oi, wi, tap_w, ci, wkey, relu_in = m
             out, wk = saved[oi], saved[wi]
             _, co, hh, ww = out.shape
             rows = b * hh * ww
@@ -1196,13 +1201,12 @@ class _VggLossFn(torch.autograd.Function):
                 if g is None:
                     g, acc = nhwc_empty(b, hh, ww, co, dev), 0
                 check(L.so_l1_loss_bwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, gout.data_ptr(), tap_w / (rows * co),
-                                       g.data_ptr(), co, rows, co, acc, _stream()), "l1_bwd")
-            # ReLU mask from the saved activation (in place), then the input gradient
-            check(L.so_act_bwd(out.data_ptr(), co, g.data_ptr(), co, g.data_ptr(), co, rows, co, ACT_RELU, 0.0, _stream()), "act_bwd")
+                                       g.data_ptr(), co, rows, co, acc, 1, _stream()), "l1_bwd")
             dx = nhwc_empty(b, hh, ww, ci, dev)
             wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
-            check(L.so_conv2d_dgrad_t(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, b, hh, ww, ci, co, 3, 3, 1, 1,
-                                      ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_t")
+            gate = saved[relu_in].data_ptr() if relu_in is not None else None  # x half = first b images of the 2b batch
+            check(L.so_conv2d_dgrad_t_gated(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, gate, b, hh, ww, ci, co, 3, 3, 1, 1,
+                                            ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_t")
             g = dx
         dxr = g if cp == c else g[:, :c]
         return (dxr, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
