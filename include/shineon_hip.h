@@ -126,10 +126,12 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
                   const float* mean, const float* stat, int stat_is_var, float eps,
                   const float* gamma, const float* beta, void* stream);
 
-/* dgamma/dbeta (BatchNorm affine, optional): overwritten, or added to when accumulate != 0 (gradient slabs). */
+/* dgamma/dbeta (BatchNorm affine, optional): overwritten, or added to when accumulate != 0 (gradient slabs).
+ * relu_gate != 0: x is the output of a ReLU (FeatureExtraction's Conv -> ReLU -> BatchNorm, warp.py:13-31) and dx is
+ * the gradient in front of that ReLU (zero where x == 0), saving the separate mask pass. */
 int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
                 long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                float* dgamma, float* dbeta, int accumulate, float* ws, void* stream);
+                float* dgamma, float* dbeta, int accumulate, int relu_gate, float* ws, void* stream);
 
 /* ---- pointwise / resampling / reductions (csrc/elementwise.hip) ---------------------------------- */
 

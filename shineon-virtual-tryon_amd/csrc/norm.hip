@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ sums) {
+                                                        const float* __restrict__ sums, int relu_gate) {
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
   const float invR = 1.0f / (float)R;
@@ -232,11 +232,13 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
     for (int i = 0; i < VEC; ++i) {
       const unsigned c = cq * VEC + i;
       const float mu = mean[(size_t)g * C + c], rs = rstd[(size_t)g * C + c];
-      const float xh = (x[(size_t)row * ldx + c] - mu) * rs;
+      const float xv = x[(size_t)row * ldx + c];
+      const float xh = (xv - mu) * rs;
       const float s1 = sums[(size_t)g * 2 * C + c], s2 = sums[(size_t)g * 2 * C + C + c];
       float v = dy[(size_t)row * lddy + c] - s1 * invR - xh * s2 * invR;
       v *= rs;
       if (gamma) v *= gamma[c];
+      if (relu_gate && !(xv > 0.f)) v = 0.f;  // x is a ReLU output: also chain through that ReLU
       dx[(size_t)row * lddx + c] = v;
     }
   }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
                                                          int lddx, unsigned R, unsigned C,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int accumulate) {
+                                                         float* __restrict__ dbeta, int accumulate, int relu_gate) {
   __shared__ float p1[32][33], p2[32][33];
   __shared__ float b1[32], b2[32];
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
   float* bo = dx + (size_t)g * R * lddx + col;
 #pragma unroll 8
   for (unsigned r = ty; r < R; r += 32) {
-    const float xh = (bx[(size_t)r * ldx] - mu) * rs;
-    bo[(size_t)r * lddx] = (bd[(size_t)r * lddy] - a - xh * b) * sc;
+    const float xv = bx[(size_t)r * ldx];
+    const float xh = (xv - mu) * rs;
+    const float v = (bd[(size_t)r * lddy] - a - xh * b) * sc;
+    bo[(size_t)r * lddx] = (relu_gate && !(xv > 0.f)) ? 0.f : v;
   }
 }
 
@@ -432,13 +436,13 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
 
 int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
                 long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                float* dgamma, float* dbeta, int accumulate, float* ws, void* stream) {
+                float* dgamma, float* dbeta, int accumulate, int relu_gate, float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
   if (dgamma && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (R <= kSmallRows) {
     hipLaunchKernelGGL(norm_small_bwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, dy, lddy, dx, lddx,
-                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate);
+                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate);
     return SO_LAUNCH_CHECK();
   }
   unsigned chunk, nchunk;
@@ -455,10 +459,10 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0)
     hipLaunchKernelGGL(norm_bwd_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,
-                       lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums);
+                       lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   else
     hipLaunchKernelGGL(norm_bwd_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, dy, lddy,
-                       dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums);
+                       dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   return SO_LAUNCH_CHECK();
 }
 

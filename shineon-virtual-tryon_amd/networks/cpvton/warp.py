@@ -36,7 +36,24 @@ class FeatureExtraction(nn.Module):
         init_weights(self.model, init_type="normal")
 
     def forward(self, x):
-        return self.model(x)
+        """nn.Sequential semantics with the Conv -> ReLU (-> BatchNorm) groups fused: the ReLU runs in the convolution's
+        epilogue, and in training its backward mask is applied by the BatchNorm backward that already reads the
+        same tensor (no separate activation kernels in either direction)."""
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, HipConv2d) and not m.fuse_relu and i + 1 < len(mods) and isinstance(mods[i + 1], HipReLU):
+                bn = mods[i + 2] if i + 2 < len(mods) and isinstance(mods[i + 2], HipBatchNorm2d) else None
+                gate = bn is not None and bn.training and torch.is_grad_enabled()
+                x = ops.conv2d(x, m.weight, m.bias, m.stride, m.padding, ops.ACT_RELU, act_grad_external=gate)
+                if bn is not None:
+                    x = bn(x, relu_gate_input=gate)
+                i += 3 if bn is not None else 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class FeatureL2Norm(nn.Module):

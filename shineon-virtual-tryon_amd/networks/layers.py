@@ -80,12 +80,14 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._shared_counter = False  # True: the owner model bumps all counters with one launch (share_bn_counters)
 
-    def forward(self, x):
+    def forward(self, x, relu_gate_input=False):
+        """relu_gate_input (training only): x is a ReLU output whose producer leaves the ReLU's backward mask to this
+        layer (see ops.batch_norm_train)."""
         if self.training:
             if not self._shared_counter:
                 self.num_batches_tracked += 1
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                        self.momentum, self.eps)
+                                        self.momentum, self.eps, relu_gate_input=relu_gate_input)
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)
 
 

@@ -261,7 +261,7 @@ class _Conv2dFn(torch.autograd.Function):
     channels are computed as op = ceil4(o) columns of which the last op - o are exactly zero."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad):
+    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False):
         L = lib()
         o, i, r, s = weight.shape
         cp, op = (i + 3) // 4 * 4, (o + 3) // 4 * 4
@@ -280,8 +280,10 @@ class _Conv2dFn(torch.autograd.Function):
             ),
             "conv2d_fprop",
         )
-        ctx.save_for_backward(xr, w, y if act != ACT_NONE else None)
-        ctx.cfg = (stride, pad, act, i, cp, op, bias is not None, tuple(weight.shape), zero_bias_grad)
+        ctx.save_for_backward(xr, w, y if act != ACT_NONE and not act_grad_external else None)
+        # act_grad_external: the consumer (a BatchNorm told so) applies the activation's mask to the gradient it sends
+        ctx.cfg = (stride, pad, ACT_NONE if act_grad_external else act, i, cp, op, bias is not None, tuple(weight.shape),
+                   zero_bias_grad)
         # parameters whose .grad is a view of the optimizer's flat slab get their gradient accumulated in place
         ctx.direct = (weight if _direct_grad_ok(weight, ohwi=True) else None,
                       bias if bias is not None and _direct_grad_ok(bias, ohwi=False) else None)
@@ -383,13 +385,15 @@ class _Conv2dFn(torch.autograd.Function):
             fork.join()
         elif need_w or need_b:
             dw, db = weight_grads(lane=0)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False):
+def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False):
     """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
-    output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed."""
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad)
+    output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
+    act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
+    (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel."""
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -516,7 +520,7 @@ class _NormFn(torch.autograd.Function):
     """InstanceNorm2d (instance=True) or BatchNorm2d training (instance=False)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps, relu_gate_input=False):
         L = lib()
         x = to_rows(x)
         n, c, h, w = x.shape
@@ -537,7 +541,7 @@ class _NormFn(torch.autograd.Function):
             "norm_fwd",
         )
         ctx.save_for_backward(x, mean, rstd, gamma)
-        ctx.cfg = (G, R)
+        ctx.cfg = (G, R, bool(relu_gate_input))
         # affine parameters living in the optimizer's flat slab get their gradients accumulated in place
         ctx.direct = (gamma, beta) if gamma is not None and _direct_grad_ok(gamma, False) and _direct_grad_ok(beta, False) else None
         return y
@@ -546,7 +550,7 @@ class _NormFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = lib()
         x, mean, rstd, gamma = ctx.saved_tensors
-        G, R = ctx.cfg
+        G, R, relu_gate = ctx.cfg
         n, c, h, w = x.shape
         dy = to_rows(dy)
         dx = nhwc_empty(n, h, w, c, x.device)
@@ -563,19 +567,21 @@ class _NormFn(torch.autograd.Function):
             L.so_norm_bwd(
                 x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
                 gamma.data_ptr() if gamma is not None else None,
-                gptr, bptr, int(ctx.direct is not None), ws.data_ptr(), _stream(),
+                gptr, bptr, int(ctx.direct is not None), int(relu_gate), ws.data_ptr(), _stream(),
             ),
             "norm_bwd",
         )
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def instance_norm(x, eps=1e-5):
     return _NormFn.apply(x, None, None, None, None, True, 0.0, eps)
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
-    return _NormFn.apply(x, gamma, beta, running_mean, running_var, False, momentum, eps)
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu_gate_input=False):
+    """relu_gate_input: x is the output of a ReLU whose producer skips its own backward mask (conv2d(...,
+    act_grad_external=True)); the returned input gradient is then the one in front of that ReLU."""
+    return _NormFn.apply(x, gamma, beta, running_mean, running_var, False, momentum, eps, relu_gate_input)
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):

@@ -167,6 +167,25 @@ def test_batch_norm_train_and_eval(ops, cuda, hw):
     assert_close(y, F.batch_norm(x, rm_c, rv_c, g, b, False, 0.1, 1e-5), atol=2e-5, what="batch_norm eval")
 
 
+@pytest.mark.parametrize("hw", [(8, 6), (40, 28)])  # single-launch norm (R <= 1024 rows) / three-kernel norm
+def test_conv_relu_batchnorm_fused_gate(ops, cuda, hw):
+    """FeatureExtraction's Conv -> ReLU -> BatchNorm group: ReLU in the conv epilogue, its backward mask applied by the
+    BatchNorm backward (conv2d(act_grad_external=True) + batch_norm_train(relu_gate_input=True))."""
+    x = rnd(2, 8, hw[0], hw[1], seed=40)
+    w, b = rnd(16, 8, 3, 3, seed=41, scale=0.15), rnd(16, seed=42, scale=0.1)
+    g, be = rnd(16, seed=43) * 0.1 + 1, rnd(16, seed=44) * 0.1
+    rm_g, rv_g = torch.zeros(16).to(cuda), torch.ones(16).to(cuda)
+    rm_c, rv_c = torch.zeros(16), torch.ones(16)
+
+    def hip(x_, w_, b_, g_, be_):
+        y = ops.conv2d(x_, w_, b_, 1, 1, ops.ACT_RELU, act_grad_external=True)
+        return ops.batch_norm_train(y, g_, be_, rm_g, rv_g, 0.1, 1e-5, relu_gate_input=True)
+
+    compare_fwd_bwd(hip, lambda x_, w_, b_, g_, be_: F.batch_norm(F.relu(F.conv2d(x_, w_, b_, padding=1)), rm_c, rv_c, g_, be_,
+                                                                   True, 0.1, 1e-5),
+                    [(x, True), (w, True), (b, True), (g, True), (be, True)], cuda, atol=2e-5, gatol=1e-4, what=f"conv+relu+bn {hw}")
+
+
 @pytest.mark.parametrize("kind,ref", [("relu", F.relu), ("gelu", F.gelu), ("leaky", lambda t: F.leaky_relu(t, 0.2))])
 @pytest.mark.parametrize("c", [8, 6])
 def test_activation_fused_into_upsample(ops, cuda, kind, ref, c):
