@@ -53,7 +53,7 @@ _SIDE = {}
 # Weight/bias gradients on a side stream, overlapping the input-gradient GEMM.  Measured on MI355X (bench.py
 # --steps 10): 289 frames/s with, 293 without — both GEMMs already fill the CUs, so sharing them only stretches
 # each kernel.  Off by default; kept as an experiment switch.
-CONCURRENT_WGRAD = False
+CONCURRENT_WGRAD = os.environ.get("SHINEON_CONCURRENT_WGRAD", "0") == "1"
 DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
 
 
