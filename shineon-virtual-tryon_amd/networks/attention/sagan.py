@@ -20,6 +20,10 @@ class SelfAttention(nn.Module):
         self.key_conv = HipConv2d(in_dim, in_dim // 8, kernel_size=1)
         self.value_conv = HipConv2d(in_dim, in_dim, kernel_size=1)
         self.gamma = nn.Parameter(torch.zeros(1))
+        # layout hint for optim.HipAdam: q/k/v weights (and biases) adjacent in the flat slab = one [2d+C, C] matrix
+        for i, conv in enumerate((self.query_conv, self.key_conv, self.value_conv)):
+            conv.weight._so_adjacent = ((id(self), "w"), i)
+            conv.bias._so_adjacent = ((id(self), "b"), i)
 
     def forward(self, x):
         return ops.self_attention(

@@ -24,7 +24,7 @@ class HipAdam(torch.optim.Optimizer):
         return [p for g in self.param_groups for p in g["params"]]
 
     def _build(self):
-        ps = self._params()
+        ps = _slab_order(self._params())
         dev = ps[0].device
         if dev.type != "cuda":
             raise RuntimeError("HipAdam needs parameters on an MI355X (model.cuda() first); no CPU fallback")
@@ -95,6 +95,26 @@ class HipAdam(torch.optim.Optimizer):
                 self._build()
             self._flat[2].copy_(sd["exp_avg"])
             self._flat[3].copy_(sd["exp_avg_sq"])
+
+
+def _slab_order(ps):
+    """Slab layout order: parameters tagged `_so_adjacent = (group_key, index)` by their module are placed next to each
+    other in index order (SelfAttention lays its query/key/value weights - and biases - out as one [2d+C, C] matrix so
+    that one GEMM serves the three projections); everything else keeps the optimizer's order."""
+    groups = {}
+    for p in ps:
+        tag = getattr(p, "_so_adjacent", None)
+        if tag is not None:
+            groups.setdefault(tag[0], []).append((tag[1], p))
+    out, done = [], set()
+    for p in ps:
+        tag = getattr(p, "_so_adjacent", None)
+        if tag is None:
+            out.append(p)
+        elif tag[0] not in done:
+            done.add(tag[0])
+            out.extend(q for _, q in sorted(groups[tag[0]], key=lambda t: t[0]))
+    return out
 
 
 def _is_dense(p):

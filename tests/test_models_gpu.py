@@ -228,3 +228,37 @@ def test_attention_head_dim_not_multiple_of_4(cuda):
     assert_close(xg.grad, xc.grad, atol=1e-4, what="attention d=5 dx")
     assert_close(sa.query_conv.weight.grad, pc["a.query_conv.weight"].grad, atol=1e-4, what="attention d=5 dWq")
     assert_close(sa.key_conv.bias.grad, pc["a.key_conv.bias"].grad, atol=1e-4, what="attention d=5 dbk")
+
+
+@pytest.mark.parametrize("c,hw", [(64, (4, 3)), (128, (8, 6))])
+def test_self_attention_fused_qkv_path(cuda, c, hw):
+    """With HipAdam's slab layout (q/k/v weights, biases and gradients adjacent) the three projections and their
+    gradients run as single GEMMs accumulating into the gradient slab; same numbers as the oracle."""
+    from oracle.procedural import procedural_state_dict
+    from shineon_virtual_tryon_amd import ops
+    from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
+    from shineon_virtual_tryon_amd.optim import HipAdam
+
+    sa = SelfAttention(c)
+    sd = procedural_state_dict({k: tuple(v.shape) for k, v in sa.state_dict().items()}, seed=11)
+    sd["gamma"] = torch.tensor([0.7])
+    sa.load_state_dict(sd)
+    sa = sa.to(cuda)
+    opt = HipAdam(sa.parameters(), lr=1e-3)
+    opt.zero_grad()
+    convs = (sa.query_conv, sa.key_conv, sa.value_conv)
+    assert ops._adjacent([m.weight for m in convs]) and ops._adjacent([m.bias.grad for m in convs])
+    x = torch.randn(2, c, hw[0], hw[1], generator=torch.Generator().manual_seed(12))
+    xg = x.clone().to(cuda).requires_grad_(True)
+    y = sa(xg)
+    assert type(y.grad_fn).__name__.startswith("_SelfAttentionQkvFn")
+    xc = x.clone().requires_grad_(True)
+    pc = {"a." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = oracle.self_attention(xc, pc, "a")
+    assert_close(y, yr, atol=2e-5, what="fused attention")
+    seed = torch.randn(yr.shape, generator=torch.Generator().manual_seed(13))
+    (y * seed.to(cuda)).sum().backward()
+    (yr * seed).sum().backward()
+    assert_close(xg.grad, xc.grad, atol=1e-4, what="fused attention dx")
+    for name, prm in sa.named_parameters():
+        assert_close(prm.grad, pc["a." + name].grad, atol=1e-4, rtol=1e-4, what=f"fused attention d{name}")
