@@ -31,7 +31,7 @@ __device__ __forceinline__ Mom mom_merge(Mom a, Mom b) {
   return r;
 }
 
-constexpr int EPT = 32;  // rows per thread per chunk
+constexpr int EPT = 8;   // rows per thread per chunk (at least)
 
 // part layout: [G][nchunk][3][C]
 __global__ __launch_bounds__(256) void stats_partial_k(const float* __restrict__ x, int ldx,
@@ -79,21 +79,21 @@ __global__ __launch_bounds__(256) void stats_partial_k(const float* __restrict__
 }
 
 // mean[g][c], rstd[g][c]; optional running-stat update (BatchNorm, G must be 1).
-__global__ __launch_bounds__(256) void stats_final_k(const float* __restrict__ part, unsigned nchunk,
+__global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ part, unsigned nchunk,
                                                      unsigned C, float eps, float* __restrict__ mean,
                                                      float* __restrict__ rstd,
                                                      float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float momentum) {
-  // 16 columns x 16 chunk-lanes per block: lane l merges chunks l, l+16, ... then the lanes are merged in
+  // 16 columns x 64 chunk-lanes per block: lane l merges chunks l, l+64, ... then the lanes are merged in
   // a fixed order through LDS (deterministic).
-  __shared__ float sn[256], sm[256], s2[256];
+  __shared__ float sn[1024], sm[1024], s2[1024];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
   Mom acc = {0.f, 0.f, 0.f};
   if (c < C) {
-#pragma unroll 8
-    for (unsigned k = ty; k < nchunk; k += 16) {
+#pragma unroll 4
+    for (unsigned k = ty; k < nchunk; k += 64) {
       const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
       acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
     }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void stats_final_k(const float* __restrict__ p
   __syncthreads();
   if (ty != 0 || c >= C) return;
   acc = Mom{0.f, 0.f, 0.f};
-  for (unsigned l = 0; l < 16; ++l) acc = mom_merge(acc, Mom{sn[l * 16 + tx], sm[l * 16 + tx], s2[l * 16 + tx]});
+  for (unsigned l = 0; l < 64; ++l) acc = mom_merge(acc, Mom{sn[l * 16 + tx], sm[l * 16 + tx], s2[l * 16 + tx]});
   const float var = acc.m2 / acc.n;
   mean[(size_t)g * C + c] = acc.mean;
   rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
@@ -126,18 +126,24 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
                                                     float eps) {
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / CQ, cq = idx - row * CQ;
     const unsigned g = row / R;
+    const unsigned c0 = cq * VEC;
+    const vec_t xv = *reinterpret_cast<const vec_t*>(x + (size_t)row * ldx + c0);
+    const vec_t mu = *reinterpret_cast<const vec_t*>(mean + (size_t)g * C + c0);
+    vec_t rs = *reinterpret_cast<const vec_t*>(rstd + (size_t)g * C + c0);
+    vec_t o;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const unsigned c = cq * VEC + i;
-      float rs = rstd[(size_t)g * C + c];
-      if (stat_is_var) rs = 1.0f / sqrtf(rs + eps);
-      float v = (x[(size_t)row * ldx + c] - mean[(size_t)g * C + c]) * rs;
-      if (gamma) v = v * gamma[c] + beta[c];
-      y[(size_t)row * ldy + c] = v;
+      float r = rs[i];
+      if (stat_is_var) r = 1.0f / sqrtf(r + eps);
+      float v = (xv[i] - mu[i]) * r;
+      if (gamma) v = v * gamma[c0 + i] + beta[c0 + i];
+      o[i] = v;
     }
+    *reinterpret_cast<vec_t*>(y + (size_t)row * ldy + c0) = o;
   }
 }
 
@@ -182,19 +188,19 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restric
 }
 
 // sums[g][2][C]; optional dgamma/dbeta (BatchNorm: G == 1) with accumulate flag.
-__global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict__ part,
+__global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict__ part,
                                                         unsigned nchunk, unsigned C,
                                                         float* __restrict__ sums,
                                                         float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int accumulate) {
-  __shared__ float sa[256], sb[256];
+  __shared__ float sa[1024], sb[1024];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
   float a = 0.f, b = 0.f;
   if (c < C) {
-#pragma unroll 8
-    for (unsigned k = ty; k < nchunk; k += 16) {
+#pragma unroll 4
+    for (unsigned k = ty; k < nchunk; k += 64) {
       const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
       a += o[c]; b += o[C + c];
     }
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256) void norm_bwd_final_k(const float* __restrict_
   __syncthreads();
   if (ty != 0 || c >= C) return;
   a = 0.f; b = 0.f;
-  for (unsigned l = 0; l < 16; ++l) { a += sa[l * 16 + tx]; b += sb[l * 16 + tx]; }
+  for (unsigned l = 0; l < 64; ++l) { a += sa[l * 16 + tx]; b += sb[l * 16 + tx]; }
   sums[(size_t)g * 2 * C + c] = a;
   sums[(size_t)g * 2 * C + C + c] = b;
   if (dgamma) {
@@ -225,22 +231,28 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
   const float invR = 1.0f / (float)R;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / CQ, cq = idx - row * CQ;
     const unsigned g = row / R;
+    const unsigned c0 = cq * VEC;
+    const vec_t xq = *reinterpret_cast<const vec_t*>(x + (size_t)row * ldx + c0);
+    const vec_t dq = *reinterpret_cast<const vec_t*>(dy + (size_t)row * lddy + c0);
+    const vec_t mq = *reinterpret_cast<const vec_t*>(mean + (size_t)g * C + c0);
+    const vec_t rq = *reinterpret_cast<const vec_t*>(rstd + (size_t)g * C + c0);
+    const vec_t s1q = *reinterpret_cast<const vec_t*>(sums + (size_t)g * 2 * C + c0);
+    const vec_t s2q = *reinterpret_cast<const vec_t*>(sums + (size_t)g * 2 * C + C + c0);
+    vec_t o;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const unsigned c = cq * VEC + i;
-      const float mu = mean[(size_t)g * C + c], rs = rstd[(size_t)g * C + c];
-      const float xv = x[(size_t)row * ldx + c];
-      const float xh = (xv - mu) * rs;
-      const float s1 = sums[(size_t)g * 2 * C + c], s2 = sums[(size_t)g * 2 * C + C + c];
-      float v = dy[(size_t)row * lddy + c] - s1 * invR - xh * s2 * invR;
-      v *= rs;
-      if (gamma) v *= gamma[c];
-      if (relu_gate && !(xv > 0.f)) v = 0.f;  // x is a ReLU output: also chain through that ReLU
-      dx[(size_t)row * lddx + c] = v;
+      const float xh = (xq[i] - mq[i]) * rq[i];
+      float v = dq[i] - s1q[i] * invR - xh * s2q[i] * invR;
+      v *= rq[i];
+      if (gamma) v *= gamma[c0 + i];
+      if (relu_gate && !(xq[i] > 0.f)) v = 0.f;  // x is a ReLU output: also chain through that ReLU
+      o[i] = v;
     }
+    *reinterpret_cast<vec_t*>(dx + (size_t)row * lddx + c0) = o;
   }
 }
 
@@ -363,6 +375,8 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
 
 constexpr long long kSmallRows = 1024;
 
+inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 inline int grid_for(long long total) {
   long long b = (total + 255) / 256;
   if (b > 8192) b = 8192;
@@ -374,8 +388,9 @@ inline void chunking(long long R, int C, unsigned& chunk, unsigned& nchunk) {
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   const unsigned RL = 256 / CPB;
   chunk = EPT * RL;
-  // keep the number of partial blocks per column tile around 256 (enough to fill the chip, cheap to merge)
-  const unsigned min_chunk = (unsigned)((R + 255) / 256);
+  // at most ~1024 partial blocks per column tile: every thread then walks a short run of rows (the loop is a chain of
+  // dependent-latency batches), and the merge kernel spreads the partials over 64 lanes per column
+  const unsigned min_chunk = (unsigned)((R + 1023) / 1024);
   if (chunk < min_chunk) chunk = (min_chunk + RL - 1) / RL * RL;
   nchunk = (unsigned)((R + chunk - 1) / chunk);
 }
@@ -409,10 +424,10 @@ int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, 
   hipLaunchKernelGGL(stats_partial_k, g1, dim3(256), 0, st, x, ldx, (unsigned)R, (unsigned)C, chunk,
                      nchunk, ws);
   dim3 g2(so_cdiv(C, 16), G);
-  hipLaunchKernelGGL(stats_final_k, g2, dim3(256), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
+  hipLaunchKernelGGL(stats_final_k, g2, dim3(1024), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
                      running_mean, running_var, momentum);
   const long long total = (long long)G * R * C;
-  if ((C & 3) == 0)
+  if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && al16(x) && al16(y) && al16(mean) && al16(rstd))
     hipLaunchKernelGGL(norm_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y, ldy,
                        (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps);
   else
@@ -454,10 +469,11 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
   hipLaunchKernelGGL(norm_bwd_partial_k, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
                      (unsigned)C, chunk, nchunk, mean, rstd, part);
   dim3 g2(so_cdiv(C, 16), G);
-  hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(256), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
+  hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
                      dbeta, accumulate);
   const long long total = (long long)G * R * C;
-  if ((C & 3) == 0)
+  if ((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && al16(x) && al16(dy) && al16(dx) && al16(mean) &&
+      al16(rstd) && al16(sums))
     hipLaunchKernelGGL(norm_bwd_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,
                        lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   else
