@@ -361,22 +361,22 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_k(const float* __restrict__ part, unsigned nchunk,
-                                                      unsigned C, float* __restrict__ out,
-                                                      int accumulate) {
-  // 16 columns x 16 chunk-lanes per block, lanes merged in fixed order (deterministic)
-  __shared__ float sh[256];
+__global__ __launch_bounds__(1024) void colsum_final_k(const float* __restrict__ part, unsigned nchunk,
+                                                       unsigned C, float* __restrict__ out,
+                                                       int accumulate) {
+  // 16 columns x 64 chunk-lanes per block, lanes merged in fixed order (deterministic)
+  __shared__ float sh[1024];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
   float s = 0.f;
   if (c < C)
 #pragma unroll 8
-    for (unsigned k = ty; k < nchunk; k += 16) s += part[(size_t)k * C + c];
+    for (unsigned k = ty; k < nchunk; k += 64) s += part[(size_t)k * C + c];
   sh[threadIdx.x] = s;
   __syncthreads();
   if (ty != 0 || c >= C) return;
   s = 0.f;
-  for (unsigned l = 0; l < 16; ++l) s += sh[l * 16 + tx];
+  for (unsigned l = 0; l < 64; ++l) s += sh[l * 16 + tx];
   out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -400,16 +400,21 @@ __global__ __launch_bounds__(1024) void colsum_small_k(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ L1 loss (mean |a-b|)
+template <int VEC>
 __global__ __launch_bounds__(256) void l1_partial_k(const float* __restrict__ a, int lda,
                                                     const float* __restrict__ b, int ldb,
                                                     unsigned rows, unsigned C,
                                                     float* __restrict__ part) {
   __shared__ float red[4];
-  const unsigned total = rows * C;
+  const unsigned CQ = C / VEC;
+  const unsigned total = rows * CQ;
   float s = 0.f;
+#pragma unroll 4
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-    const unsigned row = idx / C, c = idx - row * C;
-    s += fabsf(a[(size_t)row * lda + c] - b[(size_t)row * ldb + c]);
+    const unsigned row = idx / CQ, c = (idx - row * CQ) * VEC;
+    const Pack<VEC> av = ldp<VEC>(a + (size_t)row * lda + c), bv = ldp<VEC>(b + (size_t)row * ldb + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += fabsf(av.v[i] - bv.v[i]);
   }
   s = so_block_sum256(s, red);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
@@ -427,21 +432,29 @@ __global__ __launch_bounds__(256) void sum_final_k(const float* __restrict__ par
 }
 
 // da = sign(a-b) * gout[0] * scale ; (optionally) db = -da ; accumulate: da += ...
+template <int VEC>
 __global__ __launch_bounds__(256) void l1_bwd_k(const float* __restrict__ a, int lda,
                                                 const float* __restrict__ b, int ldb,
                                                 const float* __restrict__ gout, float scale,
                                                 float* __restrict__ da, int ldda, unsigned rows,
                                                 unsigned C, int accumulate, int relu_gate) {
-  const unsigned total = rows * C;
+  const unsigned CQ = C / VEC;
+  const unsigned total = rows * CQ;
   const float g = gout[0] * scale;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
-    const unsigned row = idx / C, c = idx - row * C;
-    const float av = a[(size_t)row * lda + c];
-    const float d = av - b[(size_t)row * ldb + c];
-    float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
-    if (relu_gate && !(av > 0.f)) v = 0.f;  // `a` is a ReLU output: chain through the ReLU in the same pass
+    const unsigned row = idx / CQ, c = (idx - row * CQ) * VEC;
+    const Pack<VEC> av = ldp<VEC>(a + (size_t)row * lda + c), bv = ldp<VEC>(b + (size_t)row * ldb + c);
     float* o = da + (size_t)row * ldda + c;
-    *o = accumulate ? *o + v : v;
+    Pack<VEC> r;
+    if (accumulate) r = ldp<VEC>(o);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float d = av.v[i] - bv.v[i];
+      float v = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+      if (relu_gate && !(av.v[i] > 0.f)) v = 0.f;  // `a` is a ReLU output: chain through the ReLU in the same pass
+      r.v[i] = accumulate ? r.v[i] + v : v;
+    }
+    stp<VEC>(o, r);
   }
 }
 
@@ -722,7 +735,7 @@ int so_maxpool2_bwd(const float* x, int ldx, const float* dy, int lddy, float* d
 long long so_colsum_ws_floats(long long rows, int C) {
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   const unsigned RL = 256 / CPB;
-  const long long chunk = 64LL * RL;
+  const long long chunk = 16LL * RL;
   return ((rows + chunk - 1) / chunk) * C;
 }
 
@@ -737,12 +750,12 @@ int so_colsum(const float* x, int ldx, long long rows, int C, float* out, int ac
   }
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   const unsigned RL = 256 / CPB;
-  const unsigned chunk = 64 * RL;
+  const unsigned chunk = 16 * RL;  // short per-thread row runs: the loop is a chain of dependent-latency batches
   const unsigned nchunk = (unsigned)((rows + chunk - 1) / chunk);
   dim3 grid(nchunk, so_cdiv(C, CPB));
   hipLaunchKernelGGL(colsum_partial_k, grid, dim3(256), 0, st, x, ldx, (unsigned)rows, (unsigned)C,
                      chunk, ws);
-  hipLaunchKernelGGL(colsum_final_k, dim3(so_cdiv(C, 16)), dim3(256), 0, st, ws, nchunk, (unsigned)C,
+  hipLaunchKernelGGL(colsum_final_k, dim3(so_cdiv(C, 16)), dim3(1024), 0, st, ws, nchunk, (unsigned)C,
                      out, accumulate);
   return SO_LAUNCH_CHECK();
 }
@@ -753,8 +766,12 @@ int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long r
   hipStream_t st = (hipStream_t)stream;
   int blocks = grid_for(rows * C);
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(l1_partial_k, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
-                     (unsigned)C, ws);
+  if (VEC_OK2(a, lda, b, ldb, C))
+    hipLaunchKernelGGL(l1_partial_k<4>, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
+                       (unsigned)C, ws);
+  else
+    hipLaunchKernelGGL(l1_partial_k<1>, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
+                       (unsigned)C, ws);
   hipLaunchKernelGGL(sum_final_k, dim3(1), dim3(256), 0, st, ws, (unsigned)blocks, scale, out,
                      accumulate);
   return SO_LAUNCH_CHECK();
@@ -763,8 +780,12 @@ int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long r
 int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
                    float* da, int ldda, long long rows, int C, int accumulate, int relu_gate, void* stream) {
   if (rows * C <= 0) return 0;
-  hipLaunchKernelGGL(l1_bwd_k, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
-                     ldb, gout, scale, da, ldda, (unsigned)rows, (unsigned)C, accumulate, relu_gate);
+  if (VEC_OK2(a, lda, b, ldb, C) && (ldda & 3) == 0 && al16(da))
+    hipLaunchKernelGGL(l1_bwd_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, gout, scale, da, ldda, (unsigned)rows, (unsigned)C, accumulate, relu_gate);
+  else
+    hipLaunchKernelGGL(l1_bwd_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, gout, scale, da, ldda, (unsigned)rows, (unsigned)C, accumulate, relu_gate);
   return SO_LAUNCH_CHECK();
 }
 

@@ -266,7 +266,10 @@ __global__ __launch_bounds__(256) void tps_grid_fwd_k(const float* __restrict__ 
 }
 
 // partial[b][blk][axis][i] = sum over the block's pixels of dgrid[b][pix][axis] * basis_i(pix)
-constexpr int TPS_PPT = 8;
+// Basis functions are processed sixteen at a time in registers; each value is reduced inside its wavefront with
+// shuffles and the four wave totals meet in LDS behind ONE barrier (the first version paid two block reductions per
+// basis function: 112 barriers per block, 61 us per launch).
+constexpr int TPS_PPT = 2;
 __global__ __launch_bounds__(256) void tps_grid_bwd_partial_k(const float* __restrict__ dgrid,
                                                               const float* __restrict__ gx,
                                                               const float* __restrict__ gy,
@@ -274,37 +277,57 @@ __global__ __launch_bounds__(256) void tps_grid_bwd_partial_k(const float* __res
                                                               const float* __restrict__ py,
                                                               float* __restrict__ part, unsigned H,
                                                               unsigned W, int NP) {
-  __shared__ float red[4];
+  __shared__ float red[4][2 * 64];
   __shared__ float spx[64], spy[64];
   const int L = NP + 3;
   const unsigned b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int t = threadIdx.x; t < NP; t += 256) { spx[t] = px[t]; spy[t] = py[t]; }
   __syncthreads();
   const unsigned HW = H * W;
   const unsigned p0 = blockIdx.x * 256u * TPS_PPT;
-  float* out = part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * L;
-  // loop over basis functions; each pass re-reads the block's (L2-resident) gradients
-  for (int i = 0; i < L; ++i) {
-    float ax = 0.f, ay = 0.f;
-    for (int q = 0; q < TPS_PPT; ++q) {
-      const unsigned pix = p0 + q * 256u + threadIdx.x;
-      if (pix < HW) {
-        const unsigned h = pix / W, w = pix - h * W;
-        const float x = gx[w], y = gy[h];
-        float basis;
-        if (i < NP) basis = tps_u(x, y, spx[i], spy[i]);
-        else if (i == NP) basis = 1.f;
-        else if (i == NP + 1) basis = x;
-        else basis = y;
-        const float2 g = *reinterpret_cast<const float2*>(dgrid + ((size_t)b * HW + pix) * 2);
-        ax += g.x * basis;
-        ay += g.y * basis;
-      }
+  float xs[TPS_PPT], ys[TPS_PPT];
+  float2 gs[TPS_PPT];
+#pragma unroll
+  for (int q = 0; q < TPS_PPT; ++q) {
+    const unsigned pix = p0 + q * 256u + threadIdx.x;
+    xs[q] = 0.f; ys[q] = 0.f; gs[q] = make_float2(0.f, 0.f);  // zero gradient: contributes nothing
+    if (pix < HW) {
+      const unsigned h = pix / W, w = pix - h * W;
+      xs[q] = gx[w]; ys[q] = gy[h];
+      gs[q] = *reinterpret_cast<const float2*>(dgrid + ((size_t)b * HW + pix) * 2);
     }
-    ax = so_block_sum256(ax, red);
-    ay = so_block_sum256(ay, red);
-    if (threadIdx.x == 0) { out[i] = ax; out[L + i] = ay; }
   }
+  for (int i0 = 0; i0 < L; i0 += 16) {
+    float ax[16], ay[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u;
+      float sx = 0.f, sy = 0.f;
+      if (i < L) {
+#pragma unroll
+        for (int q = 0; q < TPS_PPT; ++q) {
+          float basis;
+          if (i < NP) basis = tps_u(xs[q], ys[q], spx[i], spy[i]);
+          else if (i == NP) basis = 1.f;
+          else if (i == NP + 1) basis = xs[q];
+          else basis = ys[q];
+          sx += gs[q].x * basis;
+          sy += gs[q].y * basis;
+        }
+      }
+      ax[u] = so_wave_sum(sx);
+      ay[u] = so_wave_sum(sy);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (i0 + u < L) { red[wave][i0 + u] = ax[u]; red[wave][L + i0 + u] = ay[u]; }
+    }
+  }
+  __syncthreads();
+  float* out = part + ((size_t)b * gridDim.x + blockIdx.x) * 2 * L;
+  for (int t = threadIdx.x; t < 2 * L; t += 256) out[t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
 
 // dtheta[b][axis*NP + k] = sum_i Li[i][k] * (sum_blk partial[b][blk][axis][i])
@@ -317,6 +340,7 @@ __global__ __launch_bounds__(64) void tps_grid_bwd_final_k(const float* __restri
   const unsigned b = blockIdx.x;
   for (int t = threadIdx.x; t < 2 * L; t += 64) {
     float s = 0.f;
+#pragma unroll 8
     for (unsigned k = 0; k < nblk; ++k) s += part[((size_t)b * nblk + k) * 2 * L + t];
     G[t] = s;
   }
