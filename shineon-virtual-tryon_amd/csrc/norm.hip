@@ -100,9 +100,17 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
   }
   sn[threadIdx.x] = acc.n; sm[threadIdx.x] = acc.mean; s2[threadIdx.x] = acc.m2;
   __syncthreads();
+  // fixed binary tree over the 64 lanes of a column (6 levels instead of a 64-step serial chain of divisions)
+  for (unsigned stride = 32; stride >= 1; stride >>= 1) {
+    if (ty < stride) {
+      const unsigned i0 = ty * 16 + tx, i1 = (ty + stride) * 16 + tx;
+      const Mom m = mom_merge(Mom{sn[i0], sm[i0], s2[i0]}, Mom{sn[i1], sm[i1], s2[i1]});
+      sn[i0] = m.n; sm[i0] = m.mean; s2[i0] = m.m2;
+    }
+    __syncthreads();
+  }
   if (ty != 0 || c >= C) return;
-  acc = Mom{0.f, 0.f, 0.f};
-  for (unsigned l = 0; l < 64; ++l) acc = mom_merge(acc, Mom{sn[l * 16 + tx], sm[l * 16 + tx], s2[l * 16 + tx]});
+  acc = Mom{sn[tx], sm[tx], s2[tx]};
   const float var = acc.m2 / acc.n;
   mean[(size_t)g * C + c] = acc.mean;
   rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
