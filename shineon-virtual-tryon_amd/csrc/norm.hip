@@ -304,9 +304,16 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
   }
   sn[ty][tx] = cnt; sm[ty][tx] = mu; s2[ty][tx] = m2;
   __syncthreads();
+  for (unsigned stride = 16; stride >= 1; stride >>= 1) {  // fixed binary tree over the 32 row-lanes
+    if (ty < stride) {
+      const Mom m = mom_merge(Mom{sn[ty][tx], sm[ty][tx], s2[ty][tx]},
+                              Mom{sn[ty + stride][tx], sm[ty + stride][tx], s2[ty + stride][tx]});
+      sn[ty][tx] = m.n; sm[ty][tx] = m.mean; s2[ty][tx] = m.m2;
+    }
+    __syncthreads();
+  }
   if (ty == 0 && live) {
-    Mom acc = {0.f, 0.f, 0.f};
-    for (unsigned l = 0; l < 32; ++l) acc = mom_merge(acc, Mom{sn[l][tx], sm[l][tx], s2[l][tx]});
+    const Mom acc = {sn[0][tx], sm[0][tx], s2[0][tx]};
     const float var = acc.m2 / acc.n;
     const float rs = 1.0f / sqrtf(var + eps);
     mean[(size_t)g * C + col] = acc.mean;
