@@ -50,10 +50,13 @@ def workspace(device, min_bytes=0, lane=0):
 
 
 _SIDE = {}
-# Weight/bias gradients on a side stream, overlapping the input-gradient GEMM.  Measured on MI355X (bench.py
-# --steps 10): 289 frames/s with, 293 without — both GEMMs already fill the CUs, so sharing them only stretches
-# each kernel.  Off by default; kept as an experiment switch.
+# Weight/bias gradients on a side stream, overlapping the input-gradient GEMM.  Measured on MI355X (bench.py, graph
+# replay): 352 frames/s with, 361 without - both GEMMs already fill the CUs and the fork/join adds kernel boundaries.
+# Off by default; SHINEON_CONCURRENT_WGRAD=1 switches it on for experiments.
 CONCURRENT_WGRAD = os.environ.get("SHINEON_CONCURRENT_WGRAD", "0") == "1"
+# Input gradients of trainable convolutions read the OHWI weights in place (the engine transposes while staging);
+# SHINEON_DGRAD_IN_PLACE=0 goes back to a transposed copy per step (measured 0.05 ms/step slower).  The frozen VGG
+# chain always uses cached transposed weights.
 DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
 
 
