@@ -162,6 +162,14 @@ int so_upsample2x_act_fwd(const float* x, int ldx, float* y, int ldy, int Nb, in
                           float act_param, void* stream);
 int so_upsample2x_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb, int H,
                           int W, int C, int act, float act_param, void* stream);
+/* the same pair applied to the channel concatenation [x1 | x2] of a U-Net skip connection (unet.py:198 feeding
+ * unet.py:137-138 of the enclosing block) without materialising torch.cat: y = upsample(act(cat(x1, x2)));
+ * backward writes the two input gradients separately.  x2 / dx2 == NULL: single source. */
+int so_upsample2x_cat_fwd(const float* x1, int ldx1, int C1, const float* x2, int ldx2, int C2, float* y, int ldy,
+                          int Nb, int H, int W, int act, float act_param, void* stream);
+int so_upsample2x_cat_bwd(const float* x1, int ldx1, int C1, const float* x2, int ldx2, int C2, const float* dy,
+                          int lddy, float* dx1, int lddx1, float* dx2, int lddx2, int Nb, int H, int W, int act,
+                          float act_param, void* stream);
 
 /* MaxPool2d(2, 2) of VGG19 (vgg.py:9-23) */
 int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,

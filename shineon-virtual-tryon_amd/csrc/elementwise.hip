@@ -183,10 +183,13 @@ __device__ __forceinline__ void up_src(int o, int in, int& i0, int& i1, float& l
 }
 
 template <int VEC>
+// The source may be the channel concatenation [x | x2] of two tensors (U-Net skip connection): channels < C1 come
+// from x, the rest from x2 (x2 == nullptr / C1 == C: single source), so the concatenation is never materialised.
 __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict__ x, int ldx,
                                                         float* __restrict__ y, int ldy, unsigned Nb,
                                                         unsigned H, unsigned W, unsigned C, int act,
-                                                        float act_param) {
+                                                        float act_param, const float* __restrict__ x2, int ldx2,
+                                                        unsigned C1) {
   const unsigned CQ = C / VEC, Ho = 2 * H, Wo = 2 * W;
   const unsigned total = Nb * Ho * Wo * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -199,11 +202,14 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict_
     float lh0, lh1, lw0, lw1;
     up_src((int)ho, (int)H, h0, h1, lh0, lh1);
     up_src((int)wo, (int)W, w0, w1, lw0, lw1);
-    const float* base = x + (size_t)n * H * W * ldx + cq * VEC;
-    Pack<VEC> a00 = ldp<VEC>(base + ((size_t)h0 * W + w0) * ldx);
-    Pack<VEC> a01 = ldp<VEC>(base + ((size_t)h0 * W + w1) * ldx);
-    Pack<VEC> a10 = ldp<VEC>(base + ((size_t)h1 * W + w0) * ldx);
-    Pack<VEC> a11 = ldp<VEC>(base + ((size_t)h1 * W + w1) * ldx);
+    const unsigned c0 = cq * VEC;
+    const bool first = c0 < C1;
+    const int ld = first ? ldx : ldx2;
+    const float* base = (first ? x + c0 : x2 + (c0 - C1)) + (size_t)n * H * W * ld;
+    Pack<VEC> a00 = ldp<VEC>(base + ((size_t)h0 * W + w0) * ld);
+    Pack<VEC> a01 = ldp<VEC>(base + ((size_t)h0 * W + w1) * ld);
+    Pack<VEC> a10 = ldp<VEC>(base + ((size_t)h1 * W + w0) * ld);
+    Pack<VEC> a11 = ldp<VEC>(base + ((size_t)h1 * W + w1) * ld);
     if (act != SO_ACT_NONE) {  // activation of the source pixels fused in front of the interpolation
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
                                                         float* __restrict__ dx, int lddx,
                                                         unsigned Nb, unsigned H, unsigned W,
                                                         unsigned C, const float* __restrict__ x, int ldx, int act,
-                                                        float act_param) {
+                                                        float act_param, float* __restrict__ dx2, int lddx2,
+                                                        const float* __restrict__ x2, int ldx2, unsigned C1) {
   const unsigned CQ = C / VEC, Ho = 2 * H, Wo = 2 * W;
   const unsigned total = Nb * H * W * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
@@ -262,12 +269,15 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
         for (int i = 0; i < VEC; ++i) acc.v[i] += wgt * g.v[i];
       }
     }
+    const unsigned c0 = cq * VEC;
+    const bool first = c0 < C1;
+    const size_t pix = (size_t)(n * H + hi) * W + wi;
     if (act != SO_ACT_NONE) {  // chain rule through the activation fused in front of the upsample
-      const Pack<VEC> xv = ldp<VEC>(x + ((size_t)(n * H + hi) * W + wi) * ldx + cq * VEC);
+      const Pack<VEC> xv = ldp<VEC>(first ? x + pix * ldx + c0 : x2 + pix * ldx2 + (c0 - C1));
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc.v[i] *= so_actg(act, xv.v[i], act_param);
     }
-    stp<VEC>(dx + ((size_t)(n * H + hi) * W + wi) * lddx + cq * VEC, acc);
+    stp<VEC>(first ? dx + pix * lddx + c0 : dx2 + pix * lddx2 + (c0 - C1), acc);
   }
 }
 
@@ -663,43 +673,60 @@ int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* st
   return SO_LAUNCH_CHECK();
 }
 
-int so_upsample2x_act_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, int act,
-                          float act_param, void* stream) {
+int so_upsample2x_cat_fwd(const float* x1, int ldx1, int C1, const float* x2, int ldx2, int C2, float* y, int ldy,
+                          int Nb, int H, int W, int act, float act_param, void* stream) {
+  const int C = C1 + (x2 ? C2 : 0);
   const long long total = (long long)Nb * H * W * 4 * C;
   if (total <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (VEC_OK2(x, ldx, y, ldy, C))
-    hipLaunchKernelGGL(upsample2x_fwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y,
-                       ldy, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param);
+  const bool v2 = !x2 || ((C1 & 3) == 0 && (C2 & 3) == 0 && (ldx2 & 3) == 0 && al16(x2));
+  if (VEC_OK2(x1, ldx1, y, ldy, C) && v2)
+    hipLaunchKernelGGL(upsample2x_fwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x1, ldx1, y,
+                       ldy, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param, x2, ldx2, (unsigned)C1);
   else
-    hipLaunchKernelGGL(upsample2x_fwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param);
+    hipLaunchKernelGGL(upsample2x_fwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x1, ldx1, y, ldy,
+                       (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param, x2, ldx2, (unsigned)C1);
   return SO_LAUNCH_CHECK();
+}
+
+int so_upsample2x_act_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, int act,
+                          float act_param, void* stream) {
+  return so_upsample2x_cat_fwd(x, ldx, C, nullptr, 0, 0, y, ldy, Nb, H, W, act, act_param, stream);
 }
 
 int so_upsample2x_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,
                       void* stream) {
-  return so_upsample2x_act_fwd(x, ldx, y, ldy, Nb, H, W, C, SO_ACT_NONE, 0.f, stream);
+  return so_upsample2x_cat_fwd(x, ldx, C, nullptr, 0, 0, y, ldy, Nb, H, W, SO_ACT_NONE, 0.f, stream);
+}
+
+int so_upsample2x_cat_bwd(const float* x1, int ldx1, int C1, const float* x2, int ldx2, int C2, const float* dy,
+                          int lddy, float* dx1, int lddx1, float* dx2, int lddx2, int Nb, int H, int W, int act,
+                          float act_param, void* stream) {
+  const int C = C1 + (dx2 ? C2 : 0);
+  const long long total = (long long)Nb * H * W * C;
+  if (total <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool xok = act == SO_ACT_NONE || ((ldx1 & 3) == 0 && al16(x1) && (!dx2 || ((ldx2 & 3) == 0 && al16(x2))));
+  const bool v2 = !dx2 || ((C1 & 3) == 0 && (C2 & 3) == 0 && (lddx2 & 3) == 0 && al16(dx2));
+  if (VEC_OK2(dy, lddy, dx1, lddx1, C) && xok && v2)
+    hipLaunchKernelGGL(upsample2x_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, dy, lddy, dx1,
+                       lddx1, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x1, ldx1, act, act_param, dx2, lddx2, x2,
+                       ldx2, (unsigned)C1);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, dx1,
+                       lddx1, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x1, ldx1, act, act_param, dx2, lddx2, x2,
+                       ldx2, (unsigned)C1);
+  return SO_LAUNCH_CHECK();
 }
 
 int so_upsample2x_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int Nb, int H,
                           int W, int C, int act, float act_param, void* stream) {
-  const long long total = (long long)Nb * H * W * C;
-  if (total <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  const bool xok = act == SO_ACT_NONE || ((ldx & 3) == 0 && al16(x));
-  if (VEC_OK2(dy, lddy, dx, lddx, C) && xok)
-    hipLaunchKernelGGL(upsample2x_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, dy, lddy, dx,
-                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x, ldx, act, act_param);
-  else
-    hipLaunchKernelGGL(upsample2x_bwd_k<1>, dim3(grid_for(total)), dim3(256), 0, st, dy, lddy, dx,
-                       lddx, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x, ldx, act, act_param);
-  return SO_LAUNCH_CHECK();
+  return so_upsample2x_cat_bwd(x, ldx, C, nullptr, 0, 0, dy, lddy, dx, lddx, nullptr, 0, Nb, H, W, act, act_param, stream);
 }
 
 int so_upsample2x_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int H, int W, int C,
                       void* stream) {
-  return so_upsample2x_act_bwd(nullptr, 0, dy, lddy, dx, lddx, Nb, H, W, C, SO_ACT_NONE, 0.f, stream);
+  return so_upsample2x_cat_bwd(nullptr, 0, C, nullptr, 0, 0, dy, lddy, dx, lddx, nullptr, 0, Nb, H, W, SO_ACT_NONE, 0.f, stream);
 }
 
 int so_maxpool2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C,

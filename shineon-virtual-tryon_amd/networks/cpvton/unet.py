@@ -97,28 +97,51 @@ class UnetSkipConnectionBlock(nn.Module):
         self.model = nn.Sequential(*model)
 
     def forward(self, x):
+        out = self.forward_pair(x)
+        return out.cat() if isinstance(out, SkipPair) else out
+
+    def forward_pair(self, x):
+        """forward() with the skip concatenation [x | h] left as a SkipPair: the enclosing block's `act -> Upsample` reads
+        both parts directly (ops.upsample2x_bilinear_cat), so torch.cat's copy never happens on the hot path."""
         if self.outermost:
             return _run(list(self.model), x)
         mods = list(self.model)
         if self.skip_carries_activation:
             x = mods[0](x)
             mods = mods[1:]
-        return ops.cat_channels([x, _run(mods, x)])
+        return SkipPair(x, _run(mods, x))
+
+
+class SkipPair:
+    """cat([x, h], 1) of a skip connection, not yet materialised."""
+
+    __slots__ = ("x", "h")
+
+    def __init__(self, x, h):
+        self.x, self.h = x, h
+
+    def cat(self):
+        return ops.cat_channels([self.x, self.h])
 
 
 def _run(mods, h):
     """nn.Sequential semantics with one fusion: an activation module directly followed by the bilinear upsample (the up
-    path's `act -> Upsample`) runs as a single kernel."""
+    path's `act -> Upsample`) runs as a single kernel, which also consumes a pending skip concatenation in place."""
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, HipActivation) and i + 1 < len(mods) and isinstance(mods[i + 1], HipUpsample2x):
-            h = ops.upsample2x_bilinear(h, m.kind, m.param)
+            if isinstance(h, SkipPair):
+                h = ops.upsample2x_bilinear_cat(h.x, h.h, m.kind, m.param)
+            else:
+                h = ops.upsample2x_bilinear(h, m.kind, m.param)
             i += 2
         else:
-            h = m(h)
+            if isinstance(h, SkipPair):
+                h = h.cat()
+            h = m.forward_pair(h) if isinstance(m, UnetSkipConnectionBlock) else m(h)
             i += 1
-    return h
+    return h.cat() if isinstance(h, SkipPair) else h
 
 
 def _get_activation_fn(activation):

@@ -492,6 +492,42 @@ def upsample2x_bilinear(x, act=ACT_NONE, param=0.0):
     return _Upsample2xFn.apply(x, ACT_CODES[act] if not isinstance(act, int) else act, float(param))
 
 
+class _Upsample2xCatFn(torch.autograd.Function):
+    """y = upsample2x(act(cat([a, b], 1))) with the concatenation never materialised (U-Net skip connection feeding the
+    enclosing block's `act -> Upsample`); the backward pass writes the two input gradients separately."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, param):
+        a, b = to_rows(a), to_rows(b)
+        n, c1, h, w = a.shape
+        c2 = b.shape[1]
+        y = nhwc_empty(n, 2 * h, 2 * w, c1 + c2, a.device)
+        check(lib().so_upsample2x_cat_fwd(a.data_ptr(), _ld(a), c1, b.data_ptr(), _ld(b), c2, y.data_ptr(), c1 + c2, n, h, w,
+                                          act, param, _stream()), "upsample2x_cat_fwd")
+        ctx.shape = (n, c1, c2, h, w)
+        ctx.cfg = (act, param)
+        if act != ACT_NONE:
+            ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c1, c2, h, w = ctx.shape
+        act, param = ctx.cfg
+        dy = to_rows(dy)
+        da, db = nhwc_empty(n, h, w, c1, dy.device), nhwc_empty(n, h, w, c2, dy.device)
+        a, b = ctx.saved_tensors if act != ACT_NONE else (None, None)
+        check(lib().so_upsample2x_cat_bwd(a.data_ptr() if a is not None else None, _ld(a) if a is not None else 0, c1,
+                                          b.data_ptr() if b is not None else None, _ld(b) if b is not None else 0, c2,
+                                          dy.data_ptr(), _ld(dy), da.data_ptr(), c1, db.data_ptr(), c2, n, h, w, act, param,
+                                          _stream()), "upsample2x_cat_bwd")
+        return da, db, None, None
+
+
+def upsample2x_bilinear_cat(a, b, act=ACT_NONE, param=0.0):
+    return _Upsample2xCatFn.apply(a, b, ACT_CODES[act] if not isinstance(act, int) else act, float(param))
+
+
 class _MaxPool2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

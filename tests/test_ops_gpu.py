@@ -196,6 +196,16 @@ def test_activation_fused_into_upsample(ops, cuda, kind, ref, c):
                     [(x, True)], cuda, atol=2e-6, what=f"{kind}+upsample")
 
 
+@pytest.mark.parametrize("c1,c2", [(8, 12), (6, 5)])  # 16-byte path / scalar path
+@pytest.mark.parametrize("kind,ref", [("gelu", F.gelu), (None, lambda t: t)])
+def test_upsample_of_unmaterialised_concat(ops, cuda, c1, c2, kind, ref):
+    """upsample(act(cat([a, b], 1))) reading both parts in place; gradients written to the two inputs separately."""
+    a, b = rnd(2, c1, 6, 5, seed=19), rnd(2, c2, 6, 5, seed=20)
+    compare_fwd_bwd(lambda a_, b_: ops.upsample2x_bilinear_cat(a_, b_, kind),
+                    lambda a_, b_: F.interpolate(ref(torch.cat([a_, b_], 1)), scale_factor=2, mode="bilinear", align_corners=False),
+                    [(a, True), (b, True)], cuda, atol=2e-6, what=f"cat+{kind}+upsample")
+
+
 def test_upsample_maxpool_cat(ops, cuda):
     x = rnd(2, 8, 6, 5, seed=17)
     compare_fwd_bwd(ops.upsample2x_bilinear, lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False),
