@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--serial-wgrad", action="store_true", help="no side stream for weight gradients")
+    ap.add_argument("--no-pipeline", action="store_true", help="two sequential graphs (warp, then try-on) instead of the "
+                    "two-stream schedule that overlaps the warp backward pass with the try-on stage")
     ap.add_argument("--plans", default="", help="file with measured igemm plans: loaded if present (skips the "
                     "one-off tuning sweep, e.g. under a profiler), written back at the end")
     args = ap.parse_args()
@@ -174,19 +176,40 @@ def main():
         from shineon_virtual_tryon_amd.graphs import GraphedTrainStep
 
         eager_step()  # allocates workspaces, sets kernel attributes, plants the flat gradient views
-        gw = GraphedTrainStep(warp, optw, batch)
-        b2 = dict(batch)
-        b2["cloth"] = warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
-        gu = GraphedTrainStep(unet, optu, b2, alias_keys=("cloth",))
-
         pending = {"unet": False}
+        gp = gw = gu = None
+        if not args.no_pipeline:
+            from shineon_virtual_tryon_amd.graphs import GraphedChainedStep
+
+            gp = GraphedChainedStep(warp, optw, unet, optu, batch)
+        else:
+            gw = GraphedTrainStep(warp, optw, batch)
+            b2 = dict(batch)
+            b2["cloth"] = warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
+            gu = GraphedTrainStep(unet, optu, b2, alias_keys=("cloth",))
 
         def flush():
             if pending["unet"]:
                 optu.step(grad_scale=redu.finish())
                 pending["unet"] = False
 
+        def step_pipeline():
+            # side stream: warp fwd -> warp bwd -> warp all-reduce -> warp Adam, all behind the try-on graph;
+            # main stream: (previous try-on all-reduce, Adam) -> try-on fwd+bwd -> try-on all-reduce (hidden behind the
+            # next step's warp forward).  The try-on stage only waits for the warped cloth.
+            gp.launch_warp_forward()
+            flush()
+            gp.launch_tryon()
+            gp.launch_warp_backward()
+            with gp.on_side():
+                redw.start()
+                optw.step(grad_scale=redw.finish())
+            redu.start()
+            pending["unet"] = True
+
         def step():
+            if gp is not None:
+                return step_pipeline()
             # Both all-reduces are hidden behind compute: the warp gradients travel over xGMI while the try-on
             # graph runs, the try-on gradients while the NEXT step's warp graph runs (the two models share no
             # parameters, so the try-on Adam update only has to land before the next try-on forward).
@@ -275,7 +298,9 @@ def main():
                 "workload": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then "
                             "UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, "
                             "256x192",
-                "launch": "eager" if args.no_graph else "hipGraph replay of fwd+bwd per model; Adam and all-reduce eager", "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                "launch": ("eager" if args.no_graph else "two sequential hipGraphs (warp, try-on); Adam and all-reduce eager" if args.no_pipeline
+                           else "three hipGraphs on two streams: warp forward -> [try-on fwd+bwd || warp backward + its all-reduce + Adam]; "
+                                "Adam and all-reduce eager"), "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
             },
             "roofline": {
                 "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,

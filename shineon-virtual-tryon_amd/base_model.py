@@ -95,7 +95,9 @@ class BaseModel(LightningModule, abc.ABC):
 
     # ---- optimisation ----------------------------------------------------------------------------
     def configure_optimizers(self):
-        optimizer = HipAdam([p for p in self.parameters() if p.requires_grad], self.hparams.lr)
+        # modules may ask for parameters to sit next to each other in the optimizer's flat slab (SelfAttention: q/k/v)
+        adjacent = [g for m in self.modules() if hasattr(m, "adjacent_param_groups") for g in m.adjacent_param_groups()]
+        optimizer = HipAdam([p for p in self.parameters() if p.requires_grad], self.hparams.lr, adjacent=adjacent)
         scheduler = self._make_step_scheduler(optimizer)
         return [optimizer], [scheduler]
 

@@ -58,3 +58,111 @@ class GraphedTrainStep:
             self.load_batch(batch)
         self.graph.replay()
         return self.result
+
+
+class GraphedChainedStep:
+    """The chained warp -> try-on step as THREE hipGraphs replayed on two streams:
+
+        side stream : [warp forward] --ev--> [warp backward] -> (caller: all-reduce, Adam of the warp model)
+        main stream :            wait ev ->  [try-on forward + backward] -> (caller: all-reduce, Adam of the try-on model)
+
+    The warp model's backward pass - many short, low-occupancy kernels - its gradient all-reduce and its optimizer step
+    overlap the try-on stage instead of preceding it; the try-on stage only waits for the warped cloth.  The warp graphs
+    use their own scratch slabs (ops.workspace_lane) because they run concurrently with the try-on graph.
+
+    Forward and backward of the warp model are captured separately on one capture stream (autograd runs every backward
+    node on the stream of its forward op), the way torch.cuda.make_graphed_callables does."""
+
+    def __init__(self, warp, optw, unet, optu, sample_batch, warmup=2):
+        from . import ops
+
+        self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
+        self.static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}
+        sb = self.static_batch
+        self.side = torch.cuda.Stream()
+        self.fwd_done, self.tryon_done = torch.cuda.Event(), torch.cuda.Event()
+        optw.zero_grad()
+        optu.zero_grad()
+
+        def eager():
+            with ops.workspace_lane(8):
+                optw.zero_grad()
+                rw = warp.training_step(sb, 0)
+                rw.minimize.backward()
+            b2 = dict(sb)
+            b2["cloth"] = warp.warped_cloth
+            optu.zero_grad()
+            ru = unet.training_step(b2, 0)
+            ru.minimize.backward()
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+
+        cs = torch.cuda.Stream()
+        self.g_wf, self.g_wb, self.g_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with ops.workspace_lane(8):
+            with torch.cuda.graph(self.g_wf, stream=cs):
+                optw.zero_grad()
+                rw = warp.training_step(sb, 0)
+            with torch.cuda.graph(self.g_wb, stream=cs):
+                rw.minimize.backward()
+        self.result_warp = _detached(rw)
+        del rw
+        b2 = dict(sb)
+        b2["cloth"] = warp.warped_cloth  # static output of the warp-forward graph, read in place
+        with torch.cuda.graph(self.g_u):
+            optu.zero_grad()
+            ru = unet.training_step(b2, 0)
+            ru.minimize.backward()
+        self.result_tryon = _detached(ru)
+        del ru
+        self._first = True
+
+    def load_batch(self, batch):
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                self.static_batch[k].copy_(v, non_blocking=True)
+            else:
+                self.static_batch[k] = v
+
+    def launch_warp_forward(self):
+        """side stream: warp forward (after the previous try-on graph has released the warped-cloth buffer)."""
+        main = torch.cuda.current_stream()
+        if self._first:
+            self.side.wait_stream(main)
+            self._first = False
+        else:
+            self.side.wait_event(self.tryon_done)
+        with torch.cuda.stream(self.side):
+            self.g_wf.replay()
+            self.fwd_done.record(self.side)
+
+    def launch_tryon(self):
+        """main stream: try-on forward + backward once the warped cloth exists."""
+        main = torch.cuda.current_stream()
+        main.wait_event(self.fwd_done)
+        self.g_u.replay()
+        self.tryon_done.record(main)
+
+    def launch_warp_backward(self):
+        """side stream: warp backward; the caller then issues the warp all-reduce / Adam under `with self.on_side():`."""
+        with torch.cuda.stream(self.side):
+            self.g_wb.replay()
+
+    def on_side(self):
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
+def _detached(res):
+    res.minimize = res.minimize.detach()
+    res.logs = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in res.logs.items()}
+    res.prog_bar = {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in res.prog_bar.items()}
+    return res

@@ -20,10 +20,12 @@ class SelfAttention(nn.Module):
         self.key_conv = HipConv2d(in_dim, in_dim // 8, kernel_size=1)
         self.value_conv = HipConv2d(in_dim, in_dim, kernel_size=1)
         self.gamma = nn.Parameter(torch.zeros(1))
-        # layout hint for optim.HipAdam: q/k/v weights (and biases) adjacent in the flat slab = one [2d+C, C] matrix
-        for i, conv in enumerate((self.query_conv, self.key_conv, self.value_conv)):
-            conv.weight._so_adjacent = ((id(self), "w"), i)
-            conv.bias._so_adjacent = ((id(self), "b"), i)
+
+    def adjacent_param_groups(self):
+        """Layout hint for optim.HipAdam: q/k/v weights (and biases) adjacent in the flat slab = one [2d+C, C] matrix, so
+        that one GEMM serves the three projections (ops._SelfAttentionQkvFn)."""
+        convs = (self.query_conv, self.key_conv, self.value_conv)
+        return [tuple(c.weight for c in convs), tuple(c.bias for c in convs)]
 
     def forward(self, x):
         return ops.self_attention(

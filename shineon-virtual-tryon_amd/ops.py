@@ -37,10 +37,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_LANE_BASE = [0]
+
+
+class workspace_lane:
+    """Context manager: kernels issued inside use their own scratch slabs (lane offset), so that two branches of work
+    running concurrently on different streams never share split-K slabs or reduction partials."""
+
+    def __init__(self, base):
+        self.base = base
+
+    def __enter__(self):
+        self.prev = _LANE_BASE[0]
+        _LANE_BASE[0] = self.base
+
+    def __exit__(self, *exc):
+        _LANE_BASE[0] = self.prev
+
+
 def workspace(device, min_bytes=0, lane=0):
     """Per-device scratch slab (split-K slabs, reduction partials).  `lane` selects an independent slab for work
     issued on the side stream (weight gradients running concurrently with input gradients)."""
-    key = (device.type, device.index, lane)
+    key = (device.type, device.index, lane + _LANE_BASE[0])
     ws = _WS.get(key)
     need = max(_WS_BYTES, int(min_bytes))
     if ws is None or ws.numel() * 4 < need:

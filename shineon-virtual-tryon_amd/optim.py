@@ -11,20 +11,22 @@ from . import ops
 
 
 class HipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, adjacent=()):
+        """adjacent: tuples of parameters that must follow each other (in that order) in the flat slabs."""
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("HipAdam got no trainable parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._flat = None
         self._steps = 0
+        self._adjacent = [tuple(g) for g in adjacent]
 
     # ---- flat slabs ---------------------------------------------------------------------------------
     def _params(self):
         return [p for g in self.param_groups for p in g["params"]]
 
     def _build(self):
-        ps = _slab_order(self._params())
+        ps = _slab_order(self._params(), self._adjacent)
         dev = ps[0].device
         if dev.type != "cuda":
             raise RuntimeError("HipAdam needs parameters on an MI355X (model.cuda() first); no CPU fallback")
@@ -97,23 +99,25 @@ class HipAdam(torch.optim.Optimizer):
             self._flat[3].copy_(sd["exp_avg_sq"])
 
 
-def _slab_order(ps):
-    """Slab layout order: parameters tagged `_so_adjacent = (group_key, index)` by their module are placed next to each
-    other in index order (SelfAttention lays its query/key/value weights - and biases - out as one [2d+C, C] matrix so
-    that one GEMM serves the three projections); everything else keeps the optimizer's order."""
-    groups = {}
+def _slab_order(ps, adjacent=()):
+    """Slab layout order: the parameters of every group in `adjacent` are placed next to each other in the group's
+    order, at the position of the group's first member (SelfAttention lays its query/key/value weights - and biases -
+    out as one [2d+C, C] matrix so that one GEMM serves the three projections); everything else keeps the optimizer's
+    order.  Groups with a member that is not being optimized are ignored."""
+    known = {id(p) for p in ps}
+    group_of = {}
+    for g in adjacent:
+        if all(id(p) in known for p in g):
+            for p in g:
+                group_of[id(p)] = g
+    out, placed = [], set()
     for p in ps:
-        tag = getattr(p, "_so_adjacent", None)
-        if tag is not None:
-            groups.setdefault(tag[0], []).append((tag[1], p))
-    out, done = [], set()
-    for p in ps:
-        tag = getattr(p, "_so_adjacent", None)
-        if tag is None:
-            out.append(p)
-        elif tag[0] not in done:
-            done.add(tag[0])
-            out.extend(q for _, q in sorted(groups[tag[0]], key=lambda t: t[0]))
+        if id(p) in placed:
+            continue
+        g = group_of.get(id(p))
+        for q in (g if g is not None else (p,)):
+            out.append(q)
+            placed.add(id(q))
     return out
 
 

@@ -244,7 +244,7 @@ def test_self_attention_fused_qkv_path(cuda, c, hw):
     sd["gamma"] = torch.tensor([0.7])
     sa.load_state_dict(sd)
     sa = sa.to(cuda)
-    opt = HipAdam(sa.parameters(), lr=1e-3)
+    opt = HipAdam(sa.parameters(), lr=1e-3, adjacent=sa.adjacent_param_groups())
     opt.zero_grad()
     convs = (sa.query_conv, sa.key_conv, sa.value_conv)
     assert ops._adjacent([m.weight for m in convs]) and ops._adjacent([m.bias.grad for m in convs])
@@ -291,3 +291,65 @@ def test_gradients_are_bitwise_reproducible(cuda, which):
         runs.append((res.minimize.detach().clone(), opt.flat_grads.clone()))
     assert torch.equal(runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1]), float((runs[0][1] - runs[1][1]).abs().max())
+
+
+def test_two_stream_chained_schedule_matches_sequential(cuda):
+    """graphs.GraphedChainedStep (warp forward -> [try-on fwd+bwd || warp backward + Adam] on two streams, three hipGraphs)
+    trains exactly like the plain sequential loop: same losses, bit-identical parameters after three steps."""
+    import copy
+
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.graphs import GraphedChainedStep
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    torch.manual_seed(7)
+    warp_a = WarpModel(make_namespace(person_inputs=["agnostic", "cocopose"], lr=1e-3)).to(cuda).train()
+    unet_a = UnetMaskModel(make_namespace(self_attn=True, activation="gelu", lr=1e-3)).to(cuda).train()
+    for m in unet_a.modules():
+        if hasattr(m, "gamma"):
+            m.gamma.data.fill_(0.3)
+    warp_b, unet_b = copy.deepcopy(warp_a), copy.deepcopy(unet_a)
+    for m in (warp_a, unet_a, warp_b, unet_b):
+        m.global_step = 1
+    batch = synthetic_batch(2, cuda, smooth=True)
+
+    def optimizers(w, u):
+        return w.configure_optimizers()[0][0], u.configure_optimizers()[0][0]
+
+    # reference: sequential eager steps
+    optw, optu = optimizers(warp_a, unet_a)
+    seq_losses = []
+    for _ in range(3):
+        optw.zero_grad()
+        rw = warp_a.training_step(batch, 0)
+        rw.minimize.backward()
+        optw.step()
+        b2 = dict(batch)
+        b2["cloth"] = warp_a.warped_cloth.detach()
+        optu.zero_grad()
+        ru = unet_a.training_step(b2, 0)
+        ru.minimize.backward()
+        optu.step()
+        seq_losses.append((float(rw.minimize), float(ru.minimize)))
+    torch.cuda.synchronize()
+
+    # two-stream schedule on identical copies
+    optw2, optu2 = optimizers(warp_b, unet_b)
+    g = GraphedChainedStep(warp_b, optw2, unet_b, optu2, batch, warmup=1)
+    # the warm-up / capture passes above ran forward+backward but no optimizer step: parameters are still the initial ones
+    # (BatchNorm running statistics moved, which does not influence training-mode outputs)
+    pip_losses = []
+    for _ in range(3):
+        g.launch_warp_forward()
+        g.launch_tryon()
+        g.launch_warp_backward()
+        with g.on_side():
+            optw2.step()
+        optu2.step()
+        g.join()
+        torch.cuda.synchronize()
+        pip_losses.append((float(g.result_warp.minimize), float(g.result_tryon.minimize)))
+    assert pip_losses == seq_losses, (pip_losses, seq_losses)
+    assert torch.equal(optw.flat_params, optw2.flat_params)
+    assert torch.equal(optu.flat_params, optu2.flat_params)
