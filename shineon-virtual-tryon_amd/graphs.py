@@ -63,12 +63,14 @@ class GraphedTrainStep:
 class GraphedChainedStep:
     """The chained warp -> try-on step as THREE hipGraphs replayed on two streams:
 
-        side stream : [warp forward] --ev--> [warp backward] -> (caller: all-reduce, Adam of the warp model)
-        main stream :            wait ev ->  [try-on forward + backward] -> (caller: all-reduce, Adam of the try-on model)
+        side stream : [warp forward] --ev--> [warp backward] -> (caller: all-reduce, Adam of the warp model) -> next step ...
+        main stream :            wait ev ->  copy cloth -> [try-on forward + backward] -> (caller: all-reduce, Adam)
 
     The warp model's backward pass - many short, low-occupancy kernels - its gradient all-reduce and its optimizer step
-    overlap the try-on stage instead of preceding it; the try-on stage only waits for the warped cloth.  The warp graphs
-    use their own scratch slabs (ops.workspace_lane) because they run concurrently with the try-on graph.
+    overlap the try-on stage instead of preceding it; the try-on stage only waits for the warped cloth, which it copies
+    into its own buffer first, so the side stream may already run the NEXT step's warp stage while this step's try-on
+    stage is still busy (same arithmetic, only the order of independent work changes).  The two stages have separate
+    static batch buffers and the warp graphs their own scratch slabs (ops.workspace_lane).
 
     Forward and backward of the warp model are captured separately on one capture stream (autograd runs every backward
     node on the stream of its forward op), the way torch.cuda.make_graphed_callables does."""
@@ -77,10 +79,11 @@ class GraphedChainedStep:
         from . import ops
 
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
-        self.static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}
-        sb = self.static_batch
+        clone = lambda: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}
+        self.batch_warp, self.batch_tryon = clone(), clone()
+        sb = self.batch_warp
         self.side = torch.cuda.Stream()
-        self.fwd_done, self.tryon_done = torch.cuda.Event(), torch.cuda.Event()
+        self.fwd_done, self.cloth_taken = torch.cuda.Event(), torch.cuda.Event()
         optw.zero_grad()
         optu.zero_grad()
 
@@ -89,7 +92,7 @@ class GraphedChainedStep:
                 optw.zero_grad()
                 rw = warp.training_step(sb, 0)
                 rw.minimize.backward()
-            b2 = dict(sb)
+            b2 = dict(self.batch_tryon)
             b2["cloth"] = warp.warped_cloth
             optu.zero_grad()
             ru = unet.training_step(b2, 0)
@@ -113,8 +116,11 @@ class GraphedChainedStep:
                 rw.minimize.backward()
         self.result_warp = _detached(rw)
         del rw
-        b2 = dict(sb)
-        b2["cloth"] = warp.warped_cloth  # static output of the warp-forward graph, read in place
+        self.warped = warp.warped_cloth              # static output of the warp-forward graph
+        self.cloth_tryon = torch.empty_like(self.warped)  # the try-on stage's private copy (filled by launch_tryon)
+        self.cloth_tryon.copy_(self.warped)
+        b2 = dict(self.batch_tryon)
+        b2["cloth"] = self.cloth_tryon
         with torch.cuda.graph(self.g_u):
             optu.zero_grad()
             ru = unet.training_step(b2, 0)
@@ -123,31 +129,37 @@ class GraphedChainedStep:
         del ru
         self._first = True
 
-    def load_batch(self, batch):
+    @staticmethod
+    def _load(dst, batch):
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
-                self.static_batch[k].copy_(v, non_blocking=True)
+                dst[k].copy_(v, non_blocking=True)
             else:
-                self.static_batch[k] = v
+                dst[k] = v
 
-    def launch_warp_forward(self):
-        """side stream: warp forward (after the previous try-on graph has released the warped-cloth buffer)."""
-        main = torch.cuda.current_stream()
+    def launch_warp_forward(self, batch=None):
+        """side stream: (load the new batch,) warp forward.  Only waits for the previous step's try-on stage to have taken
+        its copy of the warped cloth (and, by stream order, for the previous warp backward / Adam)."""
         if self._first:
-            self.side.wait_stream(main)
+            self.side.wait_stream(torch.cuda.current_stream())
             self._first = False
         else:
-            self.side.wait_event(self.tryon_done)
+            self.side.wait_event(self.cloth_taken)
         with torch.cuda.stream(self.side):
+            if batch is not None:
+                self._load(self.batch_warp, batch)
             self.g_wf.replay()
             self.fwd_done.record(self.side)
 
-    def launch_tryon(self):
-        """main stream: try-on forward + backward once the warped cloth exists."""
+    def launch_tryon(self, batch=None):
+        """main stream: (load the new batch,) take the warped cloth, then try-on forward + backward."""
         main = torch.cuda.current_stream()
+        if batch is not None:
+            self._load(self.batch_tryon, batch)
         main.wait_event(self.fwd_done)
+        self.cloth_tryon.copy_(self.warped, non_blocking=True)
+        self.cloth_taken.record(main)
         self.g_u.replay()
-        self.tryon_done.record(main)
 
     def launch_warp_backward(self):
         """side stream: warp backward; the caller then issues the warp all-reduce / Adam under `with self.on_side():`."""
