@@ -154,6 +154,25 @@ def test_lr_schedule_matches_reference_rule():
     assert np.allclose(lrs, [1, 1, 1, 0.75, 0.5, 0.25])
 
 
+def test_slab_order_keeps_adjacent_groups_together():
+    """optim._slab_order: groups requested by modules (SelfAttention q/k/v) become contiguous runs, in group order, at
+    the position of their first member; everything else keeps its order; groups with unknown members are ignored."""
+    from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
+    from shineon_virtual_tryon_amd.optim import _slab_order
+
+    ps = [torch.nn.Parameter(torch.zeros(i + 1)) for i in range(7)]
+    order = _slab_order(ps, [(ps[1], ps[3], ps[5]), (ps[2], ps[6])])
+    assert [p.numel() for p in order] == [1, 2, 4, 6, 3, 7, 5]
+    stranger = torch.nn.Parameter(torch.zeros(9))
+    assert _slab_order(ps, [(ps[0], stranger)]) == ps
+    sa = SelfAttention(32)
+    named = dict(sa.named_parameters())
+    order = _slab_order(list(sa.parameters()), sa.adjacent_param_groups())
+    names = [next(k for k, v in named.items() if v is p) for p in order]
+    assert names == ["gamma", "query_conv.weight", "key_conv.weight", "value_conv.weight", "query_conv.bias", "key_conv.bias",
+                     "value_conv.bias"]
+
+
 def test_dense_stride_detection():
     from shineon_virtual_tryon_amd.optim import _is_dense
 
