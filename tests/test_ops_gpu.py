@@ -89,6 +89,22 @@ def test_conv2d_fwd_bwd(ops, cuda, case, force):
         lib().so_igemm_force(0, 0, 0)
 
 
+@pytest.mark.parametrize("waves", [8])
+def test_conv2d_other_wave_counts(ops, cuda, waves):
+    """The 8-wave 128x128 tile, forced (the measured plans pick it per shape)."""
+    from shineon_virtual_tryon_amd import lib
+
+    n, ci, h, w, co, k, s, p = 2, 32, 12, 10, 96, 3, 1, 1
+    x, wt, b = rnd(n, ci, h, w, seed=50), rnd(co, ci, k, k, seed=51, scale=0.06), rnd(co, seed=52, scale=0.1)
+    lib().so_igemm_force(64 if waves == 2 else 128, 64 if waves == 2 else 128, 2)
+    lib().so_igemm_force_waves(waves)
+    try:
+        compare_fwd_bwd(lambda x_, w_, b_: ops.conv2d(x_, w_, b_, s, p), lambda x_, w_, b_: F.conv2d(x_, w_, b_, stride=s, padding=p),
+                        [(x, True), (wt, True), (b, True)], cuda, atol=2e-5, rtol=1e-4, gatol=1e-4, what=f"conv waves={waves}")
+    finally:
+        lib().so_igemm_force(0, 0, 0)
+
+
 def test_conv2d_fused_relu(ops, cuda):
     x, wt, b = rnd(2, 16, 10, 8, seed=4), rnd(24, 16, 3, 3, seed=5, scale=0.1), rnd(24, seed=6, scale=0.1)
     compare_fwd_bwd(lambda x_, w_, b_: ops.conv2d(x_, w_, b_, 1, 1, ops.ACT_RELU),
