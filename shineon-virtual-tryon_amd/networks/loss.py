@@ -29,10 +29,21 @@ class VGGLoss(nn.Module):
                     cfg.append(("M",))
         return tuple(cfg), params
 
-    def forward(self, x, y):
-        if x.is_cuda and x.shape[1] == 3 and not any(p.requires_grad for p in self.vgg.parameters()):
+    def _fusable(self, t):
+        return t.is_cuda and t.shape[1] == 3 and not any(p.requires_grad for p in self.vgg.parameters())
+
+    def target_features(self, y):
+        """Tap features of the target image, to be handed to forward(x, y, y_features=...): they depend on the batch only,
+        so a training pipeline can compute them ahead of the step on another stream."""
+        if not self._fusable(y):
+            raise RuntimeError("target_features needs a 3-channel CUDA image and frozen VGG weights")
+        cfg, params = self._fused_plan()
+        return ops.vgg_target_features(y, cfg, params)
+
+    def forward(self, x, y, y_features=None):
+        if self._fusable(x):
             cfg, params = self._fused_plan()
-            return ops.vgg_perceptual_loss(x, y, cfg, params)
+            return ops.vgg_perceptual_loss(x, y, cfg, params, y_features=y_features)
         x_vgg = self.vgg(x)
         with torch.no_grad():
             y_vgg = self.vgg(y.detach())

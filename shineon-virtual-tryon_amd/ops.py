@@ -1269,23 +1269,31 @@ class _VggLossFn(torch.autograd.Function):
     The prediction x and the target y run through the stack as ONE batch (2B images: deeper layers get a
     taller GEMM), Conv3x3+ReLU is a single MFMA kernel, and the backward pass walks the x half only:
     L1 sign gradient injected at each tap, ReLU mask from the saved activations, dgrad (no wgrad: frozen).
-    `cfg` is a tuple of ("C", tap_weight or None) / ("M",) items; `params` = (w0, b0, w1, b1, ...)."""
+    `cfg` is a tuple of ("C", tap_weight or None) / ("M",) items; `params` = (w0, b0, w1, b1, ...).
+
+    With `nfeat` > 0 the first `nfeat` entries of `rest` are the target's tap features computed beforehand
+    (vgg_target_features: they depend on the batch only, so a pipeline can produce them ahead of time on another
+    stream); then only x runs through the stack and y is ignored."""
 
     @staticmethod
-    def forward(ctx, x, y, cfg, *params):
+    def forward(ctx, x, y, cfg, nfeat, *rest):
         L = lib()
-        xr, yr = to_rows(x), to_rows(y.detach())
+        yfeats, params = rest[:nfeat], rest[nfeat:]
+        xr = to_rows(x)
         b, c, h, w = xr.shape
         dev = xr.device
         cp = (c + 3) // 4 * 4
-        inp = nhwc_empty(2 * b, h, w, cp, dev)
+        nb = b if nfeat else 2 * b
+        inp = nhwc_empty(nb, h, w, cp, dev)
         half = b * h * w * cp * 4
         check(L.so_copy2d(xr.data_ptr(), _ld(xr), c, inp.data_ptr(), cp, cp, b * h * w, 0, _stream()), "copy2d")
-        check(L.so_copy2d(yr.data_ptr(), _ld(yr), c, inp.data_ptr() + half, cp, cp, b * h * w, 0, _stream()), "copy2d")
+        if not nfeat:
+            yr = to_rows(y.detach())
+            check(L.so_copy2d(yr.data_ptr(), _ld(yr), c, inp.data_ptr() + half, cp, cp, b * h * w, 0, _stream()), "copy2d")
         ws = workspace(dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         fill_(loss, 0.0)
-        cur, saved, meta, pi = inp, [], [], 0
+        cur, saved, meta, pi, ti = inp, [], [], 0, 0
         relu_in = None  # index in `saved` of the ReLU output that is the current tensor (None: image / pooled map)
         for item in cfg:
             n2, ci, hh, ww = cur.shape
@@ -1304,12 +1312,22 @@ class _VggLossFn(torch.autograd.Function):
                 check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
                                         3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
                 tap_w = item[1]
+                ytap = None  # index in `saved` of the precomputed target feature of this tap
                 if tap_w is not None:
                     rows = b * hh * ww
-                    check(L.so_l1_loss_fwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, rows, co, tap_w / (rows * co),
+                    yp = out.data_ptr() + rows * co * 4
+                    if nfeat:
+                        yf = yfeats[ti]
+                        ti += 1
+                        if tuple(yf.shape) != (b, co, hh, ww) or _ld(yf) != co:
+                            raise RuntimeError("precomputed VGG target feature has the wrong shape / layout")
+                        yp = yf.data_ptr()
+                        saved.append(yf)
+                        ytap = len(saved) - 1
+                    check(L.so_l1_loss_fwd(out.data_ptr(), co, yp, co, rows, co, tap_w / (rows * co),
                                            loss.data_ptr(), 1, ws.data_ptr(), _stream()), "l1_fwd")
                 saved.extend([out, wk])
-                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci, (weakref.ref(weight), weight._version), relu_in))
+                meta.append(("C", len(saved) - 2, len(saved) - 1, tap_w, ci, (weakref.ref(weight), weight._version), relu_in, ytap))
                 relu_in = len(saved) - 2
             cur = out
         ctx.save_for_backward(*saved)
@@ -1335,7 +1353,7 @@ class _VggLossFn(torch.autograd.Function):
                 check(L.so_maxpool2_bwd(xin.data_ptr(), ci, g.data_ptr(), ci, dx.data_ptr(), ci, b, hh, ww, ci, int(m[2]), _stream()), "maxpool2_bwd")
                 g = dx
                 continue
-            _, oi, wi, tap_w, ci, wkey, relu_in = m
+            _, oi, wi, tap_w, ci, wkey, relu_in, ytap = m
             out, wk = saved[oi], saved[wi]
             _, co, hh, ww = out.shape
             rows = b * hh * ww
@@ -1343,7 +1361,8 @@ class _VggLossFn(torch.autograd.Function):
                 acc = 1
                 if g is None:
                     g, acc = nhwc_empty(b, hh, ww, co, dev), 0
-                check(L.so_l1_loss_bwd(out.data_ptr(), co, out.data_ptr() + rows * co * 4, co, gout.data_ptr(), tap_w / (rows * co),
+                yp = saved[ytap].data_ptr() if ytap is not None else out.data_ptr() + rows * co * 4
+                check(L.so_l1_loss_bwd(out.data_ptr(), co, yp, co, gout.data_ptr(), tap_w / (rows * co),
                                        g.data_ptr(), co, rows, co, acc, 1, _stream()), "l1_bwd")
             dx = nhwc_empty(b, hh, ww, ci, dev)
             wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
@@ -1355,5 +1374,37 @@ class _VggLossFn(torch.autograd.Function):
         return (dxr, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
-def vgg_perceptual_loss(x, y, cfg, params):
-    return _VggLossFn.apply(x, y, cfg, *params)
+def vgg_perceptual_loss(x, y, cfg, params, y_features=None):
+    feats = tuple(y_features) if y_features is not None else ()
+    return _VggLossFn.apply(x, y if not feats else None, cfg, len(feats), *feats, *params)
+
+
+@torch.no_grad()
+def vgg_target_features(y, cfg, params):
+    """The tap features (relu1_1 ... relu5_1 outputs, NHWC) of the target image for vgg_perceptual_loss(y_features=...)."""
+    L = lib()
+    yr = to_rows(y.detach())
+    b, c, h, w = yr.shape
+    dev = yr.device
+    cp = (c + 3) // 4 * 4
+    cur = nhwc_empty(b, h, w, cp, dev)
+    check(L.so_copy2d(yr.data_ptr(), _ld(yr), c, cur.data_ptr(), cp, cp, b * h * w, 0, _stream()), "copy2d")
+    ws = workspace(dev)
+    feats, pi = [], 0
+    for item in cfg:
+        n2, ci, hh, ww = cur.shape
+        if item[0] == "M":
+            out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
+            check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
+        else:
+            weight, bias = params[pi], params[pi + 1]
+            pi += 2
+            co = weight.shape[0]
+            wk = _ohwi(weight, cpad=ci)
+            out = nhwc_empty(n2, hh, ww, co, dev)
+            check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
+                                    3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
+            if item[1] is not None:
+                feats.append(out)
+        cur = out
+    return feats

@@ -125,7 +125,9 @@ class UnetMaskModel(BaseModel):
             return curr, curr, torch.zeros_like(curr)
 
         loss_image_l1, l1_curr, l1_prev = both(lambda i: ops.l1_loss(pt[i], im[i]))
-        loss_image_vgg, vgg_curr, vgg_prev = both(lambda i: self.criterionVGG(pt[i], im[i]))
+        # a pipeline may have computed the target's VGG features ahead of the step (single-frame case only)
+        yf = getattr(self, "vgg_target_features", None) if n == 1 else None
+        loss_image_vgg, vgg_curr, vgg_prev = both(lambda i: self.criterionVGG(pt[i], im[i], y_features=yf))
         loss_tryon_mask_l1, m_curr, m_prev = both(lambda i: ops.l1_loss(tm[i], cm[i]))
         if fm is not None:
             loss_flow_mask_l1 = ops.tensor_sum(fm[-1]) * hp.pen_flow_mask

@@ -363,3 +363,28 @@ def test_two_stream_chained_schedule_matches_sequential(cuda):
     assert (float(g.result_warp.minimize), float(g.result_tryon.minimize)) == seq_losses[4]
     assert torch.equal(optw.flat_params, optw2.flat_params)
     assert torch.equal(optu.flat_params, optu2.flat_params)
+
+
+def test_vgg_loss_with_precomputed_target_features(cuda):
+    """VGGLoss(x, y, y_features=VGGLoss.target_features(y)) - the target branch computed ahead of time - gives the loss
+    and input gradient of the batched x||y evaluation (and of the oracle)."""
+    from shineon_virtual_tryon_amd.networks.loss import VGGLoss
+
+    torch.manual_seed(3)
+    crit = VGGLoss().to(cuda)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(2, 3, 64, 48, generator=g) * 2 - 1)
+    y = (torch.rand(2, 3, 64, 48, generator=g) * 2 - 1).to(cuda)
+    xa = x.clone().to(cuda).requires_grad_(True)
+    xb = x.clone().to(cuda).requires_grad_(True)
+    la = crit(xa, y)
+    feats = crit.target_features(y)
+    assert len(feats) == 5 and tuple(feats[0].shape) == (2, 64, 64, 48) and tuple(feats[4].shape) == (2, 512, 4, 3)
+    lb = crit(xb, y, y_features=feats)
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(la)), (float(la), float(lb))
+    assert_close(xb.grad, xa.grad.cpu(), atol=1e-7 + 1e-5 * float(xa.grad.abs().max()), what="vgg dx (precomputed target)")
+    sd = {"v." + k: v.detach().cpu() for k, v in crit.state_dict().items()}
+    lr = oracle.vgg_loss(sd, x.clone(), y.cpu(), prefix="v.vgg")
+    assert abs(float(lb) - float(lr)) <= 2e-5 * abs(float(lr)), (float(lb), float(lr))
