@@ -388,3 +388,52 @@ def test_vgg_loss_with_precomputed_target_features(cuda):
     sd = {"v." + k: v.detach().cpu() for k, v in crit.state_dict().items()}
     lr = oracle.vgg_loss(sd, x.clone(), y.cpu(), prefix="v.vgg")
     assert abs(float(lb) - float(lr)) <= 2e-5 * abs(float(lr)), (float(lb), float(lr))
+
+
+def test_trainer_fit_resume_and_test(cuda, tmp_path):
+    """trainer.Trainer drives the hooks the reference's train.py / test.py hand to Lightning: options -> registry ->
+    fit (train + validation + checkpoint) -> resume -> test (PNG writers), on the synthetic dataset."""
+    import os
+
+    from shineon_virtual_tryon_amd.options import TestOptions, TrainOptions
+    from shineon_virtual_tryon_amd.registry import find_model_using_name
+    from shineon_virtual_tryon_amd.trainer import Trainer
+
+    root = str(tmp_path / "exp")
+    argv = ["--model", "gmm", "--dataset", "synthetic", "--name", "t", "-b", "2", "--workers", "0", "--synthetic_length", "8",
+            "--experiments_dir", root, "--lr", "1e-3"]
+    opt = TrainOptions().parse(argv, interactive=False)
+    torch.manual_seed(9)
+    model = find_model_using_name(opt.model)(opt)
+    trainer = Trainer(default_root_dir=root, max_epochs=1, limit_train_batches=3, limit_val_batches=1, val_check_interval=2)
+    before = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    trainer.fit(model)
+    assert trainer.global_step == 3
+    ckpt = os.path.join(root, "checkpoints", "final.ckpt")
+    assert os.path.exists(ckpt)
+    saved = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert list(saved["state_dict"].keys()) == list(before.keys()) and saved["global_step"] == 3
+    w = "regression.linear.weight"
+    assert not torch.equal(saved["state_dict"][w], before[w])                       # it trained
+    assert int(saved["state_dict"]["extractionA.model.2.num_batches_tracked"]) == 3  # training forwards only (shared counter)
+    assert saved["optimizer_states"][0]["steps"] == 3
+
+    # resume: optimizer moments and step counters come back from the checkpoint
+    model2 = find_model_using_name(opt.model)(opt)
+    model2.load_state_dict(saved["state_dict"], strict=True)
+    t2 = Trainer(default_root_dir=root, max_epochs=1, limit_train_batches=1, limit_val_batches=1, resume_from_checkpoint=ckpt)
+    t2.fit(model2)
+    assert t2.global_step == 4 and t2.optimizer._steps == 4
+
+    # test: PNG writers under result_dir/name/<ckpt>/<datamode>/<Dataset>/
+    topt = TestOptions().parse(["--model", "gmm", "--dataset", "synthetic", "--name", "t", "-b", "2", "--workers", "0",
+                                "--synthetic_length", "4", "--checkpoint", ckpt, "--result_dir", str(tmp_path / "res")],
+                               interactive=False)
+    model3 = find_model_using_name(topt.model)(topt)
+    model3.load_state_dict(saved["state_dict"], strict=True)
+    model3.override_hparams(topt)
+    outs = Trainer(default_root_dir=root).test(model3)
+    assert len(outs) == 2
+    pngs = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path / "res")) for f in fs if f.endswith((".png", ".jpg"))]
+    # (the reference only writes warp-mask for VitonDataset: visualization.py:60-88, mirrored in io_png.save_images)
+    assert len(pngs) == 4 and all("SyntheticDataset/warp-cloth" in q for q in pngs), pngs[:4]
