@@ -437,3 +437,34 @@ def test_trainer_fit_resume_and_test(cuda, tmp_path):
     pngs = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path / "res")) for f in fs if f.endswith((".png", ".jpg"))]
     # (the reference only writes warp-mask for VitonDataset: visualization.py:60-88, mirrored in io_png.save_images)
     assert len(pngs) == 4 and all("SyntheticDataset/warp-cloth" in q for q in pngs), pngs[:4]
+
+
+def test_trainer_tryon_stage_fit_and_test(cuda, tmp_path):
+    """The try-on stage (--model tom --self_attn --activation gelu) through the same driver: one training step, the
+    interrupted-by-exception checkpoint rule is not triggered, test_step writes the try-on PNGs."""
+    import os
+
+    from shineon_virtual_tryon_amd.options import TestOptions, TrainOptions
+    from shineon_virtual_tryon_amd.registry import find_model_using_name
+    from shineon_virtual_tryon_amd.trainer import Trainer
+
+    root = str(tmp_path / "exp")
+    common = ["--model", "tom", "--dataset", "synthetic", "--name", "u", "-b", "2", "--workers", "0", "--self_attn", "--activation",
+              "gelu", "--person_inputs", "agnostic", "densepose"]
+    opt = TrainOptions().parse(common + ["--synthetic_length", "4", "--experiments_dir", root], interactive=False)
+    model = find_model_using_name(opt.model)(opt)
+    tr = Trainer(default_root_dir=root, max_epochs=1, limit_train_batches=1, limit_val_batches=1)
+    tr.fit(model)
+    ckpt = os.path.join(root, "checkpoints", "final.ckpt")
+    assert tr.global_step == 1 and os.path.exists(ckpt)
+    assert not [f for f in os.listdir(os.path.join(root, "checkpoints")) if f.startswith("interrupted")]
+    sd = torch.load(ckpt, map_location="cpu", weights_only=False)["state_dict"]
+    topt = TestOptions().parse(common + ["--synthetic_length", "2", "--checkpoint", ckpt, "--result_dir", str(tmp_path / "res")],
+                               interactive=False)
+    m2 = find_model_using_name(topt.model)(topt)
+    m2.load_state_dict(sd, strict=True)
+    m2.override_hparams(topt)
+    outs = Trainer(default_root_dir=root).test(m2)
+    assert len(outs) == 1
+    pngs = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path / "res")) for f in fs if f.endswith((".png", ".jpg"))]
+    assert len(pngs) >= 2 and all(("tryon" in q) or ("reconstruction" in q) for q in pngs), pngs[:4]
