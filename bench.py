@@ -178,7 +178,30 @@ def main():
         eager_step()  # allocates workspaces, sets kernel attributes, plants the flat gradient views
         pending = {"unet": False}
         gp = gw = gu = None
-        if not args.no_pipeline:
+        use_pipeline = not args.no_pipeline
+        if use_pipeline and world > 1:
+            # The two-stream schedule hides the warp model's gradient exchange but leaves the try-on model's exposed
+            # between two try-on graphs; the sequential schedule hides both behind the other model's graph.  Measure the
+            # try-on all-reduce on this node (same message sizes, scratch buffer) and keep the two-stream schedule only
+            # where its gain on one GPU (~1.0 ms/step) exceeds that exposure.  All ranks take the same decision (MAX).
+            scratch = torch.zeros_like(optu.flat_grads)
+            probe = GradientAllReducer(scratch)
+            for _ in range(2):
+                probe.all_reduce()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                probe.all_reduce()
+            e1.record()
+            torch.cuda.synchronize()
+            t_ms = torch.tensor([e0.elapsed_time(e1) / 5], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_ms, op=dist.ReduceOp.MAX)
+            use_pipeline = float(t_ms.item()) < 1.0
+            log(f"try-on gradient all-reduce ({scratch.numel() * 4 / 1e6:.1f} MB, {world} ranks): {float(t_ms.item()):.2f} ms -> "
+                f"{'two-stream' if use_pipeline else 'sequential'} schedule")
+            del scratch, probe
+        if use_pipeline:
             from shineon_virtual_tryon_amd.graphs import GraphedChainedStep
 
             gp = GraphedChainedStep(warp, optw, unet, optu, batch)
@@ -298,7 +321,7 @@ def main():
                 "workload": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then "
                             "UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, "
                             "256x192",
-                "launch": ("eager" if args.no_graph else "two sequential hipGraphs (warp, try-on); Adam and all-reduce eager" if args.no_pipeline
+                "launch": ("eager" if args.no_graph else "two sequential hipGraphs (warp, try-on); Adam and all-reduce eager" if gp is None
                            else "three hipGraphs on two streams: warp forward -> [try-on fwd+bwd || warp backward + its all-reduce + Adam]; "
                                 "Adam and all-reduce eager"), "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
             },
