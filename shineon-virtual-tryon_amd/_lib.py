@@ -13,6 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libshineon_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "shineon_hip.h")
 
+# Measured igemm plans (tile, waves, split-K per layer shape) committed with the package: loaded at library load so
+# that the parity tests and bench.py launch the SAME kernel instantiations, run after run (split-K factor => summation
+# order => bit pattern).  SHINEON_PLANS=<file> overrides the path, SHINEON_PLANS=none skips loading (shapes missing
+# from the file are still measured once per process unless SHINEON_AUTOTUNE=0).
+PLANS_PATH = os.path.join(_HERE, "plans", "gfx950.txt")
+PLANS_LOADED = None  # (path, number of plans) once lib() has loaded a file
+
 _lock = threading.Lock()
 _lib = None
 
@@ -73,6 +80,13 @@ def lib():
             fn.argtypes = argtypes
         # measured (tile, split-K) plans per layer shape; SHINEON_AUTOTUNE=0 falls back to the cost model
         cdll.so_igemm_autotune(0 if os.environ.get("SHINEON_AUTOTUNE", "1") == "0" else 1)
+        global PLANS_LOADED
+        plans = os.environ.get("SHINEON_PLANS", PLANS_PATH)
+        if plans and plans.lower() != "none" and os.path.exists(plans):
+            n = cdll.so_igemm_plans_load(plans.encode())
+            if n < 0:
+                raise RuntimeError(f"cannot read the igemm plans file {plans}")
+            PLANS_LOADED = (plans, n)
         _lib = cdll
         return _lib
 

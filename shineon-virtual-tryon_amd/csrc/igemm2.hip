@@ -799,7 +799,7 @@ static hipEvent_t so_prof_event() {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;  // callers skip the record (the launch itself still runs)
   return e;
 }
 
@@ -808,6 +808,7 @@ int so_prof_begin(int key, double flops, int M, int N, int K, hipStream_t stream
   SoProfRec rec;
   rec.e0 = so_prof_event();
   rec.e1 = so_prof_event();
+  if (!rec.e0 || !rec.e1) return -1;  // no events available: this launch is simply not timed
   rec.key = key;
   rec.flops = flops;
   rec.M = M; rec.N = N; rec.K = K; rec.nclass = 1; rec.splitk = 1;
@@ -836,16 +837,20 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BN);
   dim3 grid((unsigned)tiles, 1, (unsigned)(p.nclass * p.splitk));
   SoProfRec rec;
-  if (g_prof_on) {
+  bool timed = g_prof_on;
+  if (timed) {
     rec.e0 = so_prof_event();
     rec.e1 = so_prof_event();
+    timed = rec.e0 && rec.e1;
+  }
+  if (timed) {
     rec.key = MODE * 8 + (NW == 8 ? (BM == 128 ? 4 : 5) : (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0));
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
   }
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
-  if (g_prof_on) {
+  if (timed) {
     (void)hipEventRecord(rec.e1, stream);
     g_prof.push_back(rec);
   }
@@ -900,10 +905,16 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   const std::array<int, 12> key = {MODE, (int)A_MC * 2 + (int)B_MC, p.M, p.N, p.K, p.nclass, p.R, p.S, p.stride, p.C, p.Ko,
                                    p.lda * 31 + p.ldb};
   auto it = g_plan_cache.find(key);
-  if (it != g_plan_cache.end()) return so_launch_plan<MODE, A_MC, B_MC>(p, it->second, stream);
+  const long long mn = (long long)p.nclass * p.M * p.N;
+  if (it != g_plan_cache.end()) {
+    // a cached / loaded plan was measured against some workspace: re-check its slab requirement against the
+    // workspace actually handed in (a plans file from another configuration must never overrun the slab)
+    if (it->second.splitk <= 1 || (long long)it->second.splitk * mn <= ws_floats)
+      return so_launch_plan<MODE, A_MC, B_MC>(p, it->second, stream);
+    return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);
+  }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(stream, &cap);
-  const long long mn = (long long)p.nclass * p.M * p.N;
   if (cap != hipStreamCaptureStatusNone || ws_floats < 2 * mn)
     return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);
 
@@ -912,9 +923,12 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   float best_ms = 1e30f;
   const bool was_prof = g_prof_on;
   g_prof_on = false;
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    g_prof_on = was_prof;
+    return so_launch_plan<MODE, A_MC, B_MC>(p, best, stream);  // cannot measure: cost-model plan, not cached
+  }
   SoIgemm q = p;
   q.res = nullptr;
   q.ldres = 0;
@@ -946,7 +960,11 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
         (void)hipEventRecord(e0, stream);
         err = so_launch_plan<MODE, A_MC, B_MC>(q, cand, stream);
         (void)hipEventRecord(e1, stream);
-        if (!err && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);
+        if (!err) {
+          const hipError_t se = hipEventSynchronize(e1);
+          if (se != hipSuccess) err = (int)se;  // a failed tuning launch is an error, not a silent cost-model fallback
+          else (void)hipEventElapsedTime(&t, e0, e1);
+        }
         if (rep > 0 && t > 0.f && (ms == 0.f || t < ms)) ms = t;
       }
       if (!err && ms > 0.f && ms < best_ms) {

@@ -255,6 +255,46 @@ def gen_ops(out):
     print("ops.npz", len(data), "arrays")
 
 
+def gen_init(out):
+    """init_weights (models/networks/__init__.py:52-96) under a fixed torch seed: every draw comes from the global
+    generator in nn.Module.apply order, so a re-implementation that walks the same module tree reproduces the values.
+    Records checksums + the first 32 values of every tensor in the state_dict after `manual_seed(1234); init_weights`."""
+    from models.networks import init_weights
+    from models.networks.cpvton.unet import UnetGenerator
+    from models.networks.cpvton.warp import FeatureExtraction, FeatureRegression
+
+    data = {}
+
+    def record(tag, net):
+        sd = net.state_dict()
+        data[f"{tag}:keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            if v.is_floating_point():
+                data[f"{tag}:cs:{k}"] = checksums(v)
+                data[f"{tag}:head:{k}"] = v.detach().reshape(-1)[:32].numpy().copy()
+
+    for init_type in ("normal", "xavier", "kaiming"):
+        torch.manual_seed(99)
+        unet = UnetGenerator(10, 4, 6, 2, ngf=8, norm_layer=nn.InstanceNorm2d, use_self_attn=True, activation="gelu")
+        torch.manual_seed(1234)
+        init_weights(unet, init_type)
+        record(f"unet_{init_type}", unet)
+    torch.manual_seed(99)
+    fe = FeatureExtraction(22, ngf=64, n_layers=3, norm_layer=nn.BatchNorm2d)
+    torch.manual_seed(1234)
+    init_weights(fe.model, "normal")
+    record("fe_normal", fe)
+    # FeatureRegression is NOT passed through init_weights by the reference (warp.py:70-99): PyTorch defaults.  Applying
+    # it by hand shows the BatchNorm2d / Conv rules on a net that has both.
+    torch.manual_seed(99)
+    fr = FeatureRegression(input_nc=192, output_dim=50)
+    torch.manual_seed(1234)
+    init_weights(fr, "normal") if hasattr(torch.nn.init, "normal") else None
+    record("fr_normal", fr)
+    np.savez_compressed(os.path.join(out, "init_weights.npz"), **data)
+    print("init_weights.npz", len(data), "arrays")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shim()
@@ -267,3 +307,5 @@ if __name__ == "__main__":
         gen_unet(HERE)
     if "nframes" in which or not sys.argv[1:]:
         gen_unet_nframes(HERE)
+    if "init" in which or not sys.argv[1:]:
+        gen_init(HERE)

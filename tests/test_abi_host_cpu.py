@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import helpers
 from helpers import golden_state, load_golden, make_namespace, oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -223,3 +224,61 @@ def test_data_parallel_reducer_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"DP_OK {r}" in o, o
+
+
+# ------------------------------------------------------------------------------------------------ init_weights (a17)
+def _init_golden_compare(tag, net, g):
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[f"{tag}:keys"]]
+    for k, v in sd.items():
+        if not v.is_floating_point():
+            continue
+        head = v.detach().contiguous().reshape(-1)[:32].numpy()
+        np.testing.assert_array_equal(head, g[f"{tag}:head:{k}"], err_msg=f"{tag} {k} first values")
+        cs = helpers.checksums(v)
+        np.testing.assert_allclose(cs, g[f"{tag}:cs:{k}"], rtol=1e-6, atol=1e-9, err_msg=f"{tag} {k} checksums")
+
+
+@pytest.mark.parametrize("init_type", ["normal", "xavier", "kaiming"])
+def test_init_weights_matches_reference_stream(init_type):
+    """init_weights walks the module tree children-first and draws every weight from the global torch generator: with the
+    seed the golden was made with, the reference's own init_weights (models/networks/__init__.py:52-96) and ours give
+    bit-identical tensors (conv / attention-conv weights drawn, biases and InstanceNorm untouched)."""
+    from shineon_virtual_tryon_amd.networks import init_weights
+    from shineon_virtual_tryon_amd.networks.cpvton.unet import UnetGenerator
+
+    g = helpers.load_golden("init_weights.npz")
+    torch.manual_seed(99)
+    unet = UnetGenerator(10, 4, 6, 2, ngf=8, norm_layer="instance", use_self_attn=True, activation="gelu")
+    biases = {k: v.clone() for k, v in unet.state_dict().items() if k.endswith("bias") or k.endswith("gamma")}
+    torch.manual_seed(1234)
+    init_weights(unet, init_type)
+    _init_golden_compare(f"unet_{init_type}", unet, g)
+    for k, v in unet.state_dict().items():
+        if k in biases:
+            assert torch.equal(v, biases[k]), f"{k} must keep its constructor value"
+
+
+def test_init_weights_rules_on_the_gmm_networks():
+    """Conv -> N(0, .02); BatchNorm2d -> scale N(1, .02), shift 0; FeatureExtraction initialises itself in its
+    constructor, FeatureRegression keeps PyTorch's defaults (warp.py:33 vs :70-99); unknown init types raise."""
+    from shineon_virtual_tryon_amd.networks import init_weights
+    from shineon_virtual_tryon_amd.networks.cpvton.warp import FeatureExtraction, FeatureRegression
+
+    g = helpers.load_golden("init_weights.npz")
+    torch.manual_seed(99)
+    fe = FeatureExtraction(22, ngf=64, n_layers=3)
+    w = fe.model[12].weight.detach()
+    assert abs(float(w.mean())) < 2e-4 and abs(float(w.std()) - 0.02) < 2e-4      # constructor already applied the rule
+    assert abs(float(fe.model[14].weight.mean()) - 1.0) < 5e-3 and float(fe.model[14].bias.abs().max()) == 0.0
+    torch.manual_seed(1234)
+    init_weights(fe.model, "normal")
+    _init_golden_compare("fe_normal", fe, g)
+    torch.manual_seed(99)
+    fr = FeatureRegression(input_nc=192, output_dim=50)
+    w0 = fr.conv[0].weight.detach()
+    bound = 1.0 / (192 * 16) ** 0.5
+    assert float(w0.abs().max()) <= bound + 1e-7 and float(w0.std()) > 0.5 * bound / 3 ** 0.5  # kaiming_uniform(a=sqrt 5) default
+    assert torch.equal(fr.conv[1].weight, torch.ones(512))
+    with pytest.raises(NotImplementedError):
+        init_weights(fr, "orthogonal")

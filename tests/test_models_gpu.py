@@ -37,7 +37,7 @@ def test_warp_model_vs_reference_golden(cuda):
         grid, theta = model2(person, batch["cloth"])
     assert_close(theta, g["theta"], atol=2e-5, what="theta")
     assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")
-    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=2e-3, what="warped cloth")
+    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=1e-4, what="warped cloth")
     assert abs(res.minimize.item() - float(g["loss"])) < 2e-5
     gscale = float(np.abs(g["grad_linear_weight"]).max())
     assert_close(model.regression.linear.weight.grad, g["grad_linear_weight"], atol=3e-3 * gscale, what="d linear.weight")
