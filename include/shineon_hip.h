@@ -273,6 +273,43 @@ int so_resample2d_fwd(const float* in, const float* flow, float* out, int Nb, in
 int so_resample2d_bwd(const float* in, const float* flow, const float* dout, float* din, float* dflow,
                       int Nb, int C, int H, int W, void* stream);
 
+/* ---- dataset-side tensor preparation + inter-stage image wire format (csrc/dataprep.hip) ---------------- */
+
+/* visualization.py:73-77 (save_images): byte = trunc(clamp((x + 1) * 0.5 * 255, 0, 255)).  src is planar
+ * [Nb][C][HW] (chw = 1) or NHWC rows with pixel pitch ld (chw = 0); dst is [Nb][HW][C] bytes (PIL's HWC). */
+int so_quantize_u8(const float* src, int ld, int chw, void* dst, int Nb, int C, int HW, void* stream);
+
+/* transforms.ToTensor + Normalize(0.5, 0.5) (tryon_dataset.py:109-118, used for every image the datasets open,
+ * e.g. the warp-cloth PNGs read back by the try-on stage, vvt_dataset.py:139-150): src [Nb][HW][Cs] bytes,
+ * dst planar [Nb][C][HW] = (byte / 255 - 0.5) / 0.5 for the first C of the Cs interleaved channels. */
+int so_u8_to_normed(const void* src, int Cs, float* dst, int Nb, int C, int HW, void* stream);
+
+/* convert_pose_data_to_pose_map_and_vis (tryon_dataset.py:388-448): keypoints [Nb][P][3] (x, y, confidence; fp64 as
+ * json.load yields) -> pose_map [Nb][P][H][W] and the 1-channel visual im_pose [Nb][1][H][W], both in {-1, +1}; a
+ * keypoint with x > 1 and y > 1 paints the inclusive square [(int)(x - r), (int)(x + r)] x [(int)(y - r), (int)(y + r)].
+ * draw_into_map = 0 is the reference as written (its planes are converted BEFORE the square is drawn and stay -1, only
+ * im_pose shows the squares); 1 paints the squares into the one-hot planes (CP-VTON's intent).  Either output may be NULL. */
+int so_pose_map(const double* keypoints, float* pose_map, float* im_pose, int Nb, int P, int H, int W, int radius,
+                int draw_into_map, void* stream);
+
+/* get_person_head (tryon_dataset.py:323-345) and segment_cloths_from_image (datasets/util.py:6-22): with m = 1 where the
+ * LIP label's bit is set in head_bits / cloth_bits, im_head = im * m - (1 - m), im_cloth = im * m + (1 - m);
+ * parse [Nb][HW] bytes, image planar [Nb][3][HW]; outputs are planar with batch strides (elements) so they can land
+ * inside a wider buffer (agnostic = [silhouette | im_head]); shape_u8 [Nb][HW] receives (label > 0) * 255, the input
+ * of so_silhouette.  Any output may be NULL. */
+int so_parse_compose(const void* parse, const float* image, float* im_head, long long stride_head, float* im_cloth,
+                     long long stride_cloth, void* shape_u8, int head_bits, int cloth_bits, int Nb, int HW, void* stream);
+
+/* get_person_body_silhouette (tryon_dataset.py:347-369): PIL resize BILINEAR to (W/factor, H/factor) and back (Pillow's
+ * 8-bit separable resampling, 22-bit fixed point), then ToTensor + Normalize; bit-exact.  ws: so_silhouette_ws_bytes. */
+long long so_silhouette_ws_bytes(int Nb, int H, int W, int factor);
+int so_silhouette(const void* shape_u8, float* silhouette, long long stride_out, void* ws, int Nb, int H, int W, int factor,
+                  void* stream);
+
+/* get_person_flow (tryon_dataset.py:272-298): .flo payload [Nb][HW][2] (u, v interleaved) -> planar [Nb][2][HW]
+ * followed by transforms.Normalize((0.5, 0.5), (0.5, 0.5)). */
+int so_flow_decode(const float* payload, float* flow, int Nb, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

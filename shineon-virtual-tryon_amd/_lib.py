@@ -25,6 +25,8 @@ _lib = None
 
 _CTYPES = {
     "const float*": ctypes.c_void_p,
+    "const double*": ctypes.c_void_p,
+    "const void*": ctypes.c_void_p,
     "float*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
@@ -48,7 +50,7 @@ def prototypes(header_path=HEADER_PATH):
             a = re.sub(r"\s+", " ", a)
             if a == "void":
                 continue
-            mm = re.match(r"(const float\*|const char\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
+            mm = re.match(r"(const float\*|const double\*|const void\*|const char\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
             if not mm:
                 raise RuntimeError(f"cannot parse argument '{a}' of {name}")
             argtypes.append(_CTYPES[mm.group(1)])
@@ -87,6 +89,11 @@ def lib():
             if n < 0:
                 raise RuntimeError(f"cannot read the igemm plans file {plans}")
             PLANS_LOADED = (plans, n)
+        save = os.environ.get("SHINEON_PLANS_SAVE")
+        if save:  # tools: write every plan known at exit (loaded + measured in this process), to refresh the committed file
+            import atexit
+
+            atexit.register(lambda: cdll.so_igemm_plans_save(save.encode()))
         _lib = cdll
         return _lib
 

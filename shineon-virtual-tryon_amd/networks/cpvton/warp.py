@@ -91,41 +91,46 @@ class FeatureRegression(nn.Module):
         return self.linear(self.conv(x))
 
 
+def _axis(count):
+    """`count` points from -1 to 1: float64 linspace rounded to fp32."""
+    return torch.from_numpy(np.linspace(-1.0, 1.0, count)).float()
+
+
 class TpsGridGen(nn.Module):
     """Thin-plate-spline sampling grid (warp.py:116-318).  Constants are plain attributes (not buffers),
     like the reference, so they are absent from checkpoints."""
 
     def __init__(self, out_h=256, out_w=192, use_regular_grid=True, grid_size=3, reg_factor=0):
         super().__init__()
-        self.out_h, self.out_w = out_h, out_w
-        self.reg_factor = reg_factor
-        # regular output grid: float64 linspace -> fp32 (bit-exact with the reference's np.meshgrid rows)
-        self._gx = torch.from_numpy(np.linspace(-1, 1, out_w)).float()
-        self._gy = torch.from_numpy(np.linspace(-1, 1, out_h)).float()
         if not use_regular_grid:
             raise NotImplementedError("the reference only builds TpsGridGen with use_regular_grid=True")
-        axis_coords = np.linspace(-1, 1, grid_size)
+        self.out_h, self.out_w, self.reg_factor = out_h, out_w, reg_factor
         self.N = grid_size * grid_size
-        P_Y, P_X = np.meshgrid(axis_coords, axis_coords)  # P_X varies slowest (warp.py:142-145)
-        P_X = torch.FloatTensor(np.reshape(P_X, (-1, 1)))
-        P_Y = torch.FloatTensor(np.reshape(P_Y, (-1, 1)))
-        self.P_X_base, self.P_Y_base = P_X.clone(), P_Y.clone()
-        self.Li = self.compute_L_inverse(P_X, P_Y).unsqueeze(0)
+        # Output sampling lattice and control-point lattice: float64 linspace rounded once to fp32, the values the
+        # reference's np.linspace / np.meshgrid produce (warp.py:128-151); only the two axes are kept, the kernels
+        # index them per pixel.  Control points are enumerated x-major: point k sits at (axis[k // g], axis[k % g]).
+        self._gx = _axis(out_w)
+        self._gy = _axis(out_h)
+        ctrl = _axis(grid_size)
+        self.P_X_base = ctrl.repeat_interleave(grid_size).reshape(-1, 1)
+        self.P_Y_base = ctrl.repeat(grid_size).reshape(-1, 1)
+        self.Li = self.compute_L_inverse(self.P_X_base, self.P_Y_base).unsqueeze(0)
         self._dev_consts = {}
 
     @staticmethod
     def compute_L_inverse(X, Y):
-        """fp32 inverse of L = [[K, P], [P^T, 0]], K = r^2 log r^2 (warp.py:169-189)."""
-        N = X.size(0)
-        Xmat, Ymat = X.expand(N, N), Y.expand(N, N)
-        d2 = torch.pow(Xmat - Xmat.transpose(0, 1), 2) + torch.pow(Ymat - Ymat.transpose(0, 1), 2)
-        d2[d2 == 0] = 1
-        K = torch.mul(d2, torch.log(d2))
-        O = torch.ones(N, 1)
-        Z = torch.zeros(3, 3)
-        P = torch.cat((O, X, Y), 1)
-        L = torch.cat((torch.cat((K, P), 1), torch.cat((P.transpose(0, 1), Z), 1)), 0)
-        return torch.inverse(L)
+        """fp32 inverse of the TPS system matrix L = [[K, P], [P^T, 0]] with K_ij = U(|p_i - p_j|^2), U(r2) = r2 ln r2
+        (U := 0 on the diagonal via r2 -> 1) and P = [1 | x | y]   (warp.py:169-189; same LAPACK inverse)."""
+        pts = torch.cat([X.reshape(-1, 1), Y.reshape(-1, 1)], dim=1)
+        n = pts.shape[0]
+        r2 = (pts.unsqueeze(1) - pts.unsqueeze(0)).square().sum(dim=2)
+        r2 = torch.where(r2 == 0, torch.ones_like(r2), r2)
+        system = torch.zeros(n + 3, n + 3, dtype=pts.dtype)
+        system[:n, :n] = r2 * r2.log()
+        system[:n, n] = 1.0
+        system[:n, n + 1:] = pts
+        system[n:, :n] = system[:n, n:].t()
+        return torch.linalg.inv(system)
 
     def _consts(self, device):
         key = str(device)

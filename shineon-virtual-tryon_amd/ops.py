@@ -22,6 +22,7 @@ ACT_CODES = {
 }
 
 _WS = {}
+_WS_RETIRED = []  # outgrown slabs, kept alive for graphs / streams that captured their address
 _WS_BYTES = 256 << 20
 
 
@@ -62,6 +63,13 @@ def workspace(device, min_bytes=0, lane=0):
     ws = _WS.get(key)
     need = max(_WS_BYTES, int(min_bytes))
     if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            # A slab that has been handed out is never freed: captured hipGraphs hold its raw pointer and the side
+            # stream may still be using it.  Growing means a NEW, larger slab for later callers; the old one stays alive.
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"workspace lane {key[2]} would have to grow to {need} bytes during a stream capture; "
+                                   "run one eager step first so every scratch size is known before capturing")
+            _WS_RETIRED.append(ws)
         ws = torch.empty(need // 4, dtype=torch.float32, device=device)
         _WS[key] = ws
     return ws

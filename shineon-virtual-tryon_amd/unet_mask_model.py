@@ -7,13 +7,12 @@ training_step: L1(p_tryon, image) + VGG(p_tryon, image) + L1(mask, cloth_mask) +
 import argparse
 import logging
 import math
-import os.path as osp
 
 import torch
 
 from . import ops
 from .base_model import BaseModel
-from .io_png import get_save_paths, save_images
+from .io_png import StageWriter
 from .networks import init_weights
 from .networks.cpvton.unet import UnetGenerator
 from .networks.layers import HipInstanceNorm2d
@@ -155,21 +154,17 @@ class UnetMaskModel(BaseModel):
         return result
 
     def test_step(self, batch, batch_idx):
+        """Writes the generated frames under tryon/ (with --tryon_list) or reconstruction/ (unet_mask_model.py:250-282);
+        for n_frames_total > 1 the names of the LAST frame are used and only its RGB channels are saved."""
         hp = self.hparams
         batch = maybe_combine_frames_and_channels(hp, batch)
-        dataset_names, im_names = batch["dataset_name"], batch["image_name"]
-        if hp.n_frames_total > 1:
-            dataset_names = [seq[-1] for seq in dataset_names]
-            im_names = [seq[-1] for seq in im_names]
+        last = (lambda seqs: [seq[-1] for seq in seqs]) if hp.n_frames_total > 1 else (lambda names: names)
         task = "tryon" if getattr(hp, "tryon_list", None) else "reconstruction"
-        try_on_dirs = [osp.join(self.test_results_dir, d, task) for d in dataset_names]
-        save_paths = get_save_paths(try_on_dirs, im_names)
-        if all(osp.exists(s) for s in save_paths):
-            progress_bar = {"file": f"Skipping {im_names[0]}"}
-        else:
-            progress_bar = {"file": f"{im_names[0]}"}
-            person_inputs = get_and_cat_inputs(batch, hp.person_inputs)
-            cloth_inputs = get_and_cat_inputs(batch, hp.cloth_inputs)
-            _, _, self.p_tryon, _ = self.forward(person_inputs, cloth_inputs)
-            save_images(self.p_tryon[:, -RGB_CHANNELS:], im_names, try_on_dirs)
-        return {"progress_bar": progress_bar}
+        writer = StageWriter(self.test_results_dir, last(batch["dataset_name"]), last(batch["image_name"]), primary=task)
+
+        def produce():
+            _, _, self.p_tryon, _ = self.forward(get_and_cat_inputs(batch, hp.person_inputs),
+                                                 get_and_cat_inputs(batch, hp.cloth_inputs))
+            return {task: self.p_tryon[:, -RGB_CHANNELS:]}
+
+        return writer.run(produce)

@@ -4,14 +4,13 @@ forward: features(person), features(cloth) -> L2 norm -> correlation -> regressi
 training_step: L1(grid_sample(cloth, grid, border), im_cloth).
 """
 import argparse
-import os.path as osp
 from argparse import ArgumentParser
 
 from torch import nn
 
 from . import ops
 from .base_model import BaseModel
-from .io_png import get_save_paths, save_images
+from .io_png import StageWriter
 from .networks.layers import HipBatchNorm2d, share_bn_counters
 from .networks.cpvton.warp import (FeatureCorrelation, FeatureExtraction, FeatureL2Norm, FeatureRegression,
                                    TpsGridGen)
@@ -86,24 +85,18 @@ class WarpModel(BaseModel):
         return result
 
     def test_step(self, batch, batch_idx):
+        """Writes warp-cloth/ (and warp-mask/) images for the try-on stage (warp_model.py:115-152); skipped when the
+        warped cloths of this batch already exist."""
         batch = maybe_combine_frames_and_channels(self.hparams, batch)
-        dataset_names = batch["dataset_name"]
-        warp_cloth_dirs = [osp.join(self.test_results_dir, d, "warp-cloth") for d in dataset_names]
-        warp_mask_dirs = [osp.join(self.test_results_dir, d, "warp-mask") for d in dataset_names]
-        c_names = batch["cloth_name"]
-        save_paths = get_save_paths(warp_cloth_dirs, c_names)
-        if all(osp.exists(s) for s in save_paths):
-            progress_bar = {"file": f"Skipping {c_names[0]}"}
-        else:
-            progress_bar = {"file": c_names[0]}
-            c, cm = batch["cloth"], batch["cloth_mask"]
-            person_inputs = get_and_cat_inputs(batch, self.hparams.person_inputs)
-            cloth_inputs = get_and_cat_inputs(batch, self.hparams.cloth_inputs)
-            grid, theta = self.forward(person_inputs, cloth_inputs)
-            self.warped_cloth = ops.grid_sample(c, grid, padding_mode="border")
-            warped_mask = ops.grid_sample(cm, grid, padding_mode="zeros")
+        writer = StageWriter(self.test_results_dir, batch["dataset_name"], batch["cloth_name"], primary="warp-cloth")
+
+        def produce():
+            grid, _ = self.forward(get_and_cat_inputs(batch, self.hparams.person_inputs),
+                                   get_and_cat_inputs(batch, self.hparams.cloth_inputs))
+            self.warped_cloth = ops.grid_sample(batch["cloth"], grid, padding_mode="border")
+            warped_mask = ops.grid_sample(batch["cloth_mask"], grid, padding_mode="zeros")
             if "grid_vis" in batch:
                 self.warped_grid = ops.grid_sample(batch["grid_vis"], grid, padding_mode="zeros")
-            save_images(self.warped_cloth, c_names, warp_cloth_dirs)
-            save_images(warped_mask * 2 - 1, c_names, warp_mask_dirs)
-        return {"progress_bar": progress_bar}
+            return {"warp-cloth": self.warped_cloth, "warp-mask": warped_mask * 2 - 1}
+
+        return writer.run(produce)

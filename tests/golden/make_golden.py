@@ -295,6 +295,130 @@ def gen_init(out):
     print("init_weights.npz", len(data), "arrays")
 
 
+def _real_transforms():
+    """Working stand-ins for the three torchvision transforms the dataset code composes (torchvision is absent): ToTensor
+    (PIL uint8 -> CHW float / 255), Normalize (in-place (t - mean) / std, which raises on a channel-count mismatch exactly
+    like torchvision's in-place broadcast does - the reference relies on that exception to fall back to its gray
+    transform), CenterCrop (identity at the native size)."""
+    from PIL import Image
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.array(pic, copy=True)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            return torch.from_numpy(a).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean, dtype=torch.float32), torch.tensor(std, dtype=torch.float32)
+
+        def __call__(self, t):
+            t = t.clone()
+            return t.sub_(self.mean[:, None, None]).div_(self.std[:, None, None])
+
+    class CenterCrop:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            th, tw = self.size
+            w, h = img.size if isinstance(img, Image.Image) else (img.shape[-1], img.shape[-2])
+            if (h, w) == (th, tw):
+                return img
+            top, left = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))
+            return img.crop((left, top, left + tw, top + th))
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    return ToTensor, Normalize, CenterCrop, Compose
+
+
+def synthetic_raw_sample(seed, h, w):
+    """Raw dataset inputs: a blocky LIP parse map, a low-entropy RGB image, 18 keypoints (some missing, some at the
+    borders, fractional), a .flo payload."""
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, 20, size=(h // 8 + 1, w // 8 + 1)).astype(np.uint8)
+    labels[rng.random(labels.shape) < 0.35] = 0
+    parse = np.kron(labels, np.ones((8, 8), np.uint8))[:h, :w]
+    parse = np.roll(parse, (3, 5), (0, 1))
+    tiles = rng.integers(0, 256, size=(h // 4 + 1, w // 4 + 1, 3)).astype(np.uint8)
+    image = np.kron(tiles, np.ones((4, 4, 1), np.uint8))[:h, :w]
+    kp = np.zeros((18, 3), np.float64)
+    kp[:, 0] = rng.uniform(-4, w + 4, 18)
+    kp[:, 1] = rng.uniform(-4, h + 4, 18)
+    kp[:, 2] = rng.uniform(0, 1, 18)
+    kp[3] = 0.0                      # undetected joint
+    kp[5, :2] = (0.6, h / 2)         # x <= 1: skipped
+    kp[7, :2] = (w - 1.25, 2.75)     # clipped at two borders
+    kp[9, :2] = (37.0, 41.0)         # integer coordinates
+    flow = rng.normal(0, 2, size=(h, w, 2)).astype(np.float32)
+    flow = np.round(flow * 4) / 4    # low entropy (keeps the fixture small), still exercises (x - 0.5) / 0.5
+    return parse, image, kp, flow.astype(np.float32)
+
+
+def gen_dataprep(out):
+    """Dataset-side tensor preparation through the reference's own TryonDataset methods."""
+    import tempfile
+
+    from PIL import Image
+
+    from oracle import dataprep_oracle as dpo
+    ToTensor, Normalize, CenterCrop, Compose = _real_transforms()
+    sys.modules["models.flownet2_pytorch.utils.flow_utils"].readFlow = lambda path: dpo.read_flo(open(path, "rb").read())
+    import datasets.tryon_dataset as td
+    from datasets.util import segment_cloths_from_image
+
+    td.readFlow = sys.modules["models.flownet2_pytorch.utils.flow_utils"].readFlow
+    data = {}
+    for tag, (h, w), seed in (("full", (256, 192), 5), ("small", (80, 48), 6)):
+        parse, image, kp, flow = synthetic_raw_sample(seed, h, w)
+        crop = CenterCrop((h, w))
+        ds = types.SimpleNamespace(
+            opt=types.SimpleNamespace(visualize_flow=False, fine_height=h, fine_width=w), fine_height=h, fine_width=w, radius=5,
+            center_crop=crop, to_tensor_and_norm_rgb=Compose([crop, ToTensor(), Normalize((0.5,) * 3, (0.5,) * 3)]),
+            to_tensor_and_norm_gray=Compose([crop, ToTensor(), Normalize([0.5], [0.5])]),
+            flow_norm=Normalize((0.5, 0.5), (0.5, 0.5)))
+        im = ds.to_tensor_and_norm_rgb(Image.fromarray(image))
+        head = td.TryonDataset.get_person_head(ds, im, parse)
+        cloth = segment_cloths_from_image(im, parse)
+        sil = td.TryonDataset.get_person_body_silhouette(ds, parse)
+        ds.convert = None
+        pm, vis = td.TryonDataset.convert_pose_data_to_pose_map_and_vis(ds, kp)
+        pm0, vis0 = td.TryonDataset.convert_pose_data_to_pose_map_and_vis(ds, None)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "f.flo")
+            with open(path, "wb") as f:
+                f.write(np.float32(202021.25).tobytes() + np.int32(w).tobytes() + np.int32(h).tobytes() + flow.tobytes())
+            ds.get_person_flow_path = lambda index: path
+            ft, _ = td.TryonDataset.get_person_flow(ds, 0)
+        data.update({f"{tag}:parse": parse, f"{tag}:image_u8": image, f"{tag}:keypoints": kp, f"{tag}:flow_payload": flow,
+                     f"{tag}:image": im.numpy(), f"{tag}:im_head": head.numpy(), f"{tag}:im_cloth": cloth.numpy(),
+                     f"{tag}:silhouette": sil.numpy(), f"{tag}:pose_map": pm.numpy(), f"{tag}:im_cocopose": vis.numpy(),
+                     f"{tag}:pose_map_none": pm0.numpy(), f"{tag}:im_cocopose_none": vis0.numpy(), f"{tag}:flow": ft.numpy()})
+        # the PIL-drawn squares themselves (what draw.rectangle paints), for the draw_into_map=1 mode of the kernel
+        one = Image.new("L", (w, h))
+        from PIL import ImageDraw
+        squares = []
+        for i in range(18):
+            one_map = Image.new("L", (w, h))
+            if kp[i, 0] > 1 and kp[i, 1] > 1:
+                ImageDraw.Draw(one_map).rectangle((kp[i, 0] - 5, kp[i, 1] - 5, kp[i, 0] + 5, kp[i, 1] + 5), "white", "white")
+            squares.append(np.array(one_map))
+        data[f"{tag}:pil_squares"] = np.stack(squares)
+        print(tag, "pose_map unique", np.unique(pm.numpy()), "im_cocopose unique", np.unique(vis.numpy()),
+              "silhouette range", float(sil.min()), float(sil.max()))
+    np.savez_compressed(os.path.join(out, "dataprep.npz"), **data)
+    print("dataprep.npz", len(data), "arrays", os.path.getsize(os.path.join(out, "dataprep.npz")), "bytes")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shim()
@@ -309,3 +433,5 @@ if __name__ == "__main__":
         gen_unet_nframes(HERE)
     if "init" in which or not sys.argv[1:]:
         gen_init(HERE)
+    if "dataprep" in which or not sys.argv[1:]:
+        gen_dataprep(HERE)

@@ -37,7 +37,12 @@ def test_warp_model_vs_reference_golden(cuda):
         grid, theta = model2(person, batch["cloth"])
     assert_close(theta, g["theta"], atol=2e-5, what="theta")
     assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")
-    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=1e-4, what="warped cloth")
+    # warped cloth: bilinear sampling amplifies the <= 5e-5 grid difference by the image slope (up to ~2.5 per unit of
+    # normalised coordinate for the band-limited fixture): 1.2e-4 at 3 of the 4608 golden samples.  The sampling itself is
+    # exact: ATen's grid_sample on OUR grid reproduces our output to 1e-5 (and the integer taps are bit-exact).
+    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=2e-4, what="warped cloth")
+    resampled = oracle.grid_sample(batch["cloth"].cpu(), grid.cpu(), "border")  # model2 == model: the same grid
+    assert_close(model.warped_cloth, resampled, atol=1e-5, what="grid_sample(cloth, OUR grid) vs ATen on the same grid")
     assert abs(res.minimize.item() - float(g["loss"])) < 2e-5
     gscale = float(np.abs(g["grad_linear_weight"]).max())
     assert_close(model.regression.linear.weight.grad, g["grad_linear_weight"], atol=3e-3 * gscale, what="d linear.weight")

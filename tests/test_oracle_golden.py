@@ -185,3 +185,51 @@ def test_unet_mask_three_frames_flow_warp():
     out["loss/G"].backward()
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=f"n3 {k}", floor=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ dataset-side prep (f3)
+@pytest.mark.parametrize("tag", ["full", "small"])
+def test_dataprep_oracle_bit_exact_vs_reference(tag):
+    """oracle/dataprep_oracle.py against the reference's own TryonDataset methods (tests/golden/dataprep.npz): every
+    derived tensor bit for bit - ToTensor/Normalize, head / cloth isolation, the PIL-resampled silhouette, the pose
+    one-hot planes (all -1 in the reference as written) and their visual, the flow normalisation."""
+    from oracle import dataprep_oracle as dpo
+
+    g = load_golden("dataprep.npz")
+    parse, image_u8, kp, payload = (g[f"{tag}:{k}"] for k in ("parse", "image_u8", "keypoints", "flow_payload"))
+    h, w = parse.shape
+    im = dpo.u8_to_normed(image_u8)
+    np.testing.assert_array_equal(im, g[f"{tag}:image"])
+    head, cloth = dpo.head_and_cloth(im, parse)
+    np.testing.assert_array_equal(head, g[f"{tag}:im_head"])
+    np.testing.assert_array_equal(cloth, g[f"{tag}:im_cloth"])
+    np.testing.assert_array_equal(dpo.silhouette(parse), g[f"{tag}:silhouette"])
+    pm, vis = dpo.pose_map(kp, h, w, 5)
+    np.testing.assert_array_equal(pm, g[f"{tag}:pose_map"])
+    np.testing.assert_array_equal(vis, g[f"{tag}:im_cocopose"])
+    pm0, vis0 = dpo.pose_map(None, h, w, 5)
+    np.testing.assert_array_equal(pm0, g[f"{tag}:pose_map_none"])
+    np.testing.assert_array_equal(vis0, g[f"{tag}:im_cocopose_none"])
+    # CP-VTON's intended one-hot planes == what PIL's draw.rectangle paints, plane by plane
+    pm1, _ = dpo.pose_map(kp, h, w, 5, draw_into_map=True)
+    np.testing.assert_array_equal(pm1, g[f"{tag}:pil_squares"].astype(np.float32) / 255 * 2 - 1)
+    np.testing.assert_array_equal(dpo.flow_tensor(payload), g[f"{tag}:flow"])
+    raw = np.float32(202021.25).tobytes() + np.int32(w).tobytes() + np.int32(h).tobytes() + payload.tobytes()
+    np.testing.assert_array_equal(dpo.read_flo(raw), payload)
+
+
+def test_png_wire_format_round_trip_rule():
+    """quantise (visualization.py:73-77) then ToTensor+Normalize: the bytes survive, the floats come back within 1/255*2."""
+    from oracle import dataprep_oracle as dpo
+
+    rng = np.random.default_rng(3)
+    t = rng.uniform(-1.2, 1.2, size=(3, 16, 12)).astype(np.float32)
+    q = dpo.quantise_u8(t)
+    assert q.dtype == np.uint8 and q.shape == (16, 12, 3)
+    np.testing.assert_array_equal(q, oracle.png_quantise(torch.from_numpy(t)).transpose(1, 2, 0))
+    back = dpo.u8_to_normed(q)
+    # truncation is NOT idempotent: byte b reads back as (b/255 - .5)/.5, whose re-quantisation is b or b - 1
+    again = dpo.quantise_u8(back).astype(np.int32)
+    assert set(np.unique(q.astype(np.int32) - again)) <= {0, 1}
+    inside = np.abs(t) <= 1
+    assert np.abs(back - t)[inside].max() <= 2.0 / 255 + 1e-6

@@ -121,6 +121,18 @@ def compare_all_gradients(model, ref32, ref64, what, rel=GRAD_REL):
     return n
 
 
+def assert_close_either(ours, ref32, ref64, atol, what):
+    """Every element within atol of the fp32 oracle OR of the fp64 evaluation of the same graph (an fp32 reference and an
+    fp32 implementation each sit up to their own round-off away from the exact value, on either side of it)."""
+    o = ours.detach().cpu().double()
+    d = torch.minimum((o - ref32.detach().double()).abs(), (o - ref64.detach().double()).abs())
+    bad = d > atol
+    d32 = float((o - ref32.detach().double()).abs().max())
+    print(f"[{what}] max |ours - fp32 ref| {d32:.3e}, max |ours - fp64| {float((o - ref64.double()).abs().max()):.3e}, "
+          f"max |fp32 ref - fp64| {float((ref32.double() - ref64.double()).abs().max()):.3e}")
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} elements further than {atol} from both the fp32 and the fp64 oracle (max {float(d.max()):.3e})"
+
+
 def _build(cls, cuda, **hp):
     model = cls(make_namespace(**hp))
     sd = procedural_state_dict(shapes_of(model.state_dict()))
@@ -250,12 +262,13 @@ def test_c5_full_size_five_frames_flow_warp_vs_oracle(cuda):
     flat = {k: (v.reshape(v.shape[0], -1, *v.shape[3:]) if isinstance(v, torch.Tensor) and v.dim() == 5 else v)
             for k, v in batch_cpu.items()}
     p32, ref = oracle_unet(sd, flat, ohp)
-    p64, _ = oracle_unet(sd, flat, ohp, torch.float64)
+    p64, ref64 = oracle_unet(sd, flat, ohp, torch.float64)
     cat = lambda ts: torch.cat([t.contiguous() for t in ts], 1)  # noqa: E731
-    assert_close(cat(model.p_rendereds), ref["p_rendereds"], atol=1e-4, what="C5 p_rendereds")
-    assert_close(cat(model.tryon_masks), ref["tryon_masks"], atol=1e-4, what="C5 tryon_masks")
-    assert_close(cat(model.flow_masks), ref["flow_masks"], atol=1e-4, what="C5 flow_masks")
-    assert_close(cat(model.p_tryons), ref["p_tryons"], atol=1e-4, what="C5 p_tryons")
+    # 154 M parameters, K up to 12 024 per output: the fp32 reference and the fp32 HIP path each land within ~6e-5 of the
+    # exact value; an element passes when it is within 1e-4 of the fp32 oracle or of its fp64 evaluation
+    for name, ours in (("p_rendereds", cat(model.p_rendereds)), ("tryon_masks", cat(model.tryon_masks)),
+                       ("flow_masks", cat(model.flow_masks)), ("p_tryons", cat(model.p_tryons))):
+        assert_close_either(ours, ref[name], ref64[name], 1e-4, f"C5 {name}")
     for k in ("loss/G", "loss/G/l1", "loss/G/vgg", "loss/G/tryon_mask_l1", "loss/G/flow_mask_l1"):
         r = float(ref[k])
         assert abs(float(res.logs[k]) - r) <= 2e-5 + 3e-5 * abs(r), (k, float(res.logs[k]), r)
