@@ -4,15 +4,18 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is the chained warp -> try-on training step of SURVEY.md §8d (C4 at the BASELINE batch size):
-WarpModel (GMM) training step, then UnetMaskModel (self-attention, num_attn=2, GELU, L1 + VGG + mask
-loss) training step on the detached warped cloth, each with its Adam update; under N > 1 each rank works
-on its own 4 frames (weak scaling) and gradients are mean-all-reduced over RCCL.
+--config c4 (default, the headline): a "step" is the chained warp -> try-on training step of SURVEY.md §8d (C4 at the
+BASELINE batch size): WarpModel (GMM) training step, then UnetMaskModel (self-attention, num_attn=2, GELU, L1 + VGG +
+mask loss) training step on the detached warped cloth, each with its Adam update.
+--config c2 / c3: BASELINE config 2 (WarpModel alone) / config 3 (UnetMaskModel alone), same protocol.
+Under N > 1 each rank works on its own frames (weak scaling) and gradients are mean-all-reduced over RCCL.
 Inputs are synthetic (seed 420) and resident in HBM before the timed region; weights are random-init.
 
-Rank 0 prints ONE JSON line.  `roofline` is the live HIP-event measurement of the dominant MFMA kernel
-(algorithmic FLOPs / summed kernel time inside the timed region); `cpu_baseline` is the oracle (a CPU
-restatement of the reference, kind "port") timed on this host's cores on a bounded sample.
+The step that is timed is the PRODUCT's step: shineon_virtual_tryon_amd.trainer.ChainedTrainStep / TrainStep, the same
+engines Trainer.fit drives.  Rank 0 prints ONE JSON line.  `roofline` carries the live HIP-event measurement of the
+dominant MFMA kernel, the step-level fraction (algorithmic FLOPs of the whole step / step time / fp32-MFMA peak) and an
+`hbm` table (GB/s vs 8 TB/s) for the bandwidth-bound kernels; `cpu_baseline` is the oracle (a CPU restatement of the
+reference, kind "port") timed on this host's cores: 2 warm-up + >= 5 timed steps, median.
 """
 import argparse
 import ctypes
@@ -29,19 +32,28 @@ sys.path.insert(0, ROOT)
 
 import shineon_virtual_tryon_amd as pkg  # noqa: E402
 from shineon_virtual_tryon_amd.data import synthetic_batch  # noqa: E402
-from shineon_virtual_tryon_amd.trainer import GradientAllReducer, broadcast_parameters, init_distributed  # noqa: E402
+from shineon_virtual_tryon_amd.trainer import Trainer, TrainStep, broadcast_parameters  # noqa: E402
 from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel  # noqa: E402
 from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
+# algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
+GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8}
+WORKLOADS = {
+    "c4": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then UnetMaskModel "
+          "(self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, 256x192",
+    "c2": "BASELINE config 2: WarpModel (GMM feature-extract + correlation + TPS grid_sample) fwd+bwd+Adam, 256x192",
+    "c3": "BASELINE config 3: UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam, 256x192",
+}
 
 
 def hparams(**kw):
     base = dict(n_frames_total=1, cloth_inputs=["cloth"], is_train=True, ngf=64, grid_size=5, fine_height=256,
                 fine_width=192, self_attn=True, num_attn=2, flow_warp=False, activation="gelu", display_count=10 ** 9,
-                pen_flow_mask=1.0, lr=1e-4, keep_epochs=5, decay_epochs=5)
+                pen_flow_mask=1.0, lr=1e-4, keep_epochs=5, decay_epochs=5, allow_random_vgg=True)
     base.update(kw)
     return argparse.Namespace(**base)
 
@@ -63,51 +75,119 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(batch_size, iters=2):
-    """The oracle (CPU restatement of the reference path) on this host's cores: same chained step."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(config, batch_size, iters=5, warmup=2, budget_s=45.0):
+    """The oracle (CPU restatement of the reference path) on this host's cores: the same step as the GPU leg,
+    2 warm-up + >= 5 timed steps, median (SURVEY 8d / BASELINE.md §3).  Bounded: the timed loop stops early once
+    `budget_s` is spent (never below 3 timed steps)."""
     from oracle import shineon_oracle as oracle
     from oracle.procedural import procedural_state_dict, shapes_of
 
     torch.set_num_threads(usable_cores())
-    log(f"cpu_baseline: {torch.get_num_threads()} threads")
-    warp_sd = procedural_state_dict(shapes_of(WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).state_dict()))
-    unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).state_dict()))
-    wp = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in warp_sd.items()}
-    up = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in unet_sd.items()}
-    optw = torch.optim.Adam([v for v in wp.values() if v.requires_grad], 1e-4)
-    optu = torch.optim.Adam([v for v in up.values() if v.requires_grad], 1e-4)
+    log(f"cpu_baseline: {torch.get_num_threads()} threads on {cpu_model()}")
     batch = synthetic_batch(batch_size, "cpu")
-    consts = oracle.tps_constants(256, 192, 5)
-    whp = dict(person_inputs=["agnostic", "cocopose"], cloth_inputs=["cloth"])
-    uhp = dict(n_frames_total=1, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], self_attn=True,
-               num_attn=2, activation="gelu", flow_warp=False)
+    steps = []
+    if config in ("c2", "c4"):
+        warp_sd = procedural_state_dict(shapes_of(WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).state_dict()))
+        wp = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in warp_sd.items()}
+        optw = torch.optim.Adam([v for v in wp.values() if v.requires_grad], 1e-4)
+        consts = oracle.tps_constants(256, 192, 5)
+        whp = dict(person_inputs=["agnostic", "cocopose"], cloth_inputs=["cloth"])
+    if config in ("c3", "c4"):
+        unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).state_dict()))
+        up = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in unet_sd.items()}
+        optu = torch.optim.Adam([v for v in up.values() if v.requires_grad], 1e-4)
+        uhp = dict(n_frames_total=1, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], self_attn=True,
+                   num_attn=2, activation="gelu", flow_warp=False)
 
     def step():
-        optw.zero_grad()
-        out = oracle.warp_losses(wp, batch, whp, consts)
-        out["loss/G"].backward()
-        optw.step()
-        b2 = dict(batch)
-        b2["cloth"] = out["warped_cloth"].detach()
-        optu.zero_grad()
-        oracle.unet_mask_losses(up, b2, uhp)["loss/G"].backward()
-        optu.step()
+        b2 = batch
+        if config in ("c2", "c4"):
+            optw.zero_grad()
+            out = oracle.warp_losses(wp, batch, whp, consts)
+            out["loss/G"].backward()
+            optw.step()
+            b2 = dict(batch)
+            b2["cloth"] = out["warped_cloth"].detach()
+        if config in ("c3", "c4"):
+            optu.zero_grad()
+            oracle.unet_mask_losses(up, b2, uhp)["loss/G"].backward()
+            optu.step()
 
-    t0 = time.perf_counter()
-    step()
-    warm = time.perf_counter() - t0
-    log(f"cpu_baseline: warm-up step {warm:.2f} s")
-    if warm > 15.0:  # bounded sample: keep the default run within minutes on a slow host
-        dt, note = warm, "1 chained step (the warm-up itself; host too slow for more)"
-    else:
+    t_begin = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    while len(steps) < iters or (len(steps) < 3):
         t0 = time.perf_counter()
-        for _ in range(iters):
-            step()
-        dt = (time.perf_counter() - t0) / iters
-        note = f"1 warm-up + {iters} timed chained steps"
-    return {"value": batch_size / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{note} (WarpModel + UnetMaskModel fwd+bwd+Adam, bs={batch_size}, 256x192) "
-                      f"with PyTorch CPU fp32, {dt * 1e3:.0f} ms/step"}
+        step()
+        steps.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > budget_s and len(steps) >= 3:
+            break
+    steps.sort()
+    med = steps[len(steps) // 2]
+    what = {"c4": "chained steps (WarpModel + UnetMaskModel fwd+bwd+Adam", "c2": "WarpModel steps (fwd+bwd+Adam",
+            "c3": "UnetMaskModel steps (fwd+bwd+Adam"}[config]
+    return {"value": batch_size / med, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "sample": f"{warmup} warm-up + {len(steps)} timed {what}, bs={batch_size}, 256x192) with PyTorch CPU fp32, "
+                      f"median {med * 1e3:.0f} ms/step (min {steps[0] * 1e3:.0f}, max {steps[-1] * 1e3:.0f})"}
+
+
+def hbm_table(dev, batch_size):
+    """GB/s of the bandwidth-bound kernels at the step's own tensor sizes (stand-alone launches, 20 repetitions, HIP
+    events on the launch stream), algorithmic bytes per DESIGN.md §3.2, against the 8 TB/s HBM peak."""
+    from shineon_virtual_tryon_amd import ops
+
+    L = pkg.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    f = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    n = batch_size
+    cases = {}
+    npar = 41_704_826  # trainable parameters of the two models (19.06 M + 22.65 M)
+    p, g, m, v = (f(npar) for _ in range(4))
+    cases["adam_step (41.7 M params, 28 B/param)"] = (
+        lambda: L.so_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), npar, 1e-4, 0.9, 0.999, 1e-8, 3, 1.0, st),
+        npar * 28)
+    x = f(n * 128 * 96, 128)
+    y = torch.empty(n * 256 * 192, 128, device=dev)
+    cases["upsample2x bilinear (128x96 -> 256x192, C=128)"] = (
+        lambda: L.so_upsample2x_fwd(x.data_ptr(), 128, y.data_ptr(), 128, n, 128, 96, 128, st), (x.numel() + y.numel()) * 4)
+    xn = ops.nhwc_empty(n, 128, 96, 64, dev)
+    cases["instance norm fwd (128x96, C=64; 12 B/elem)"] = (lambda: ops.instance_norm(xn), xn.numel() * 12)
+    xv = f(2 * n * 256 * 192, 64)
+    yv = torch.empty(2 * n * 128 * 96, 64, device=dev)
+    cases["maxpool2x2 (VGG relu1_2, 2B images, C=64)"] = (
+        lambda: L.so_maxpool2_fwd(xv.data_ptr(), 64, yv.data_ptr(), 64, 2 * n, 256, 192, 64, st), (xv.numel() + yv.numel()) * 4)
+    src = f(n, 22, 256, 192)
+    dst = torch.empty(n * 256 * 192, 24, device=dev)
+    cases["nchw -> nhwc (person input, 22 -> 24 ch)"] = (
+        lambda: L.so_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), 24, n, 22, 24, 256 * 192, st), (src.numel() + dst.numel()) * 4)
+    a_ = f(n * 256 * 192, 64)
+    b_ = torch.empty_like(a_)
+    cases["gelu fwd (256x192 rows, C=64; 8 B/elem)"] = (
+        lambda: L.so_act_fwd(a_.data_ptr(), 64, b_.data_ptr(), 64, a_.shape[0], 64, 3, 0.0, st), a_.numel() * 8)
+    out = {}
+    for name, (fn, nbytes) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out[name] = {"bytes": nbytes, "avg_us": round(us, 2), "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / PEAK_HBM_GBS, 3)}
+    return out
 
 
 def main():
@@ -116,133 +196,60 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (BASELINE: 4)")
+    ap.add_argument("--config", choices=("c4", "c2", "c3"), default="c4",
+                    help="c4: chained warp->try-on step (headline); c2: WarpModel alone; c3: UnetMaskModel alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
-    ap.add_argument("--cpu-iters", type=int, default=2)
-    ap.add_argument("--serial-wgrad", action="store_true", help="no side stream for weight gradients")
-    ap.add_argument("--no-pipeline", action="store_true", help="two sequential graphs (warp, then try-on) instead of the "
-                    "two-stream schedule that overlaps the warp backward pass with the try-on stage")
-    ap.add_argument("--plans", default="", help="file with measured igemm plans: loaded if present (skips the "
-                    "one-off tuning sweep, e.g. under a profiler), written back at the end")
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--no-pipeline", action="store_true", help="c4: two sequential graphs (warp, then try-on) instead of "
+                    "the two-stream schedule that overlaps the warp backward pass with the try-on stage")
+    ap.add_argument("--no-hbm-table", action="store_true")
+    ap.add_argument("--plans", default="", help="extra igemm plans file: loaded on top of the committed one if present, "
+                    "and every plan known at the end is written back to it")
     args = ap.parse_args()
 
-    rank, world = init_distributed()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    trainer = Trainer(graph=not args.no_graph, overlap=True)   # joins the process group under torchrun
+    rank, world = trainer.rank, trainer.world
+    dev = trainer.device
     L = pkg.lib()
+    from shineon_virtual_tryon_amd import _lib as so_lib
+
+    if so_lib.PLANS_LOADED:
+        log(f"{so_lib.PLANS_LOADED[1]} committed igemm plans loaded from {os.path.relpath(so_lib.PLANS_LOADED[0], ROOT)}")
     if args.plans and os.path.exists(args.plans):
         log(f"loaded {L.so_igemm_plans_load(args.plans.encode())} igemm plans from {args.plans}")
 
     torch.manual_seed(420)
-    warp = WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).to(dev).train()
-    unet = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).to(dev).train()
-    warp.global_step = unet.global_step = 1
-    broadcast_parameters(warp)
-    broadcast_parameters(unet)
-    (optw,), _ = warp.configure_optimizers()
-    (optu,), _ = unet.configure_optimizers()
-    optw.zero_grad()
-    optu.zero_grad()
-    redw, redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads)
     batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch)
+    cfg = args.config
+    warp = unet = None
+    if cfg in ("c2", "c4"):
+        warp = WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).to(dev).train()
+        warp.global_step = 1
+    if cfg in ("c3", "c4"):
+        unet = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).to(dev).train()
+        unet.global_step = 1
 
-    def eager_step():
-        optw.zero_grad()
-        res = warp.training_step(batch, 0)
-        res.minimize.backward()
-        optw.step(grad_scale=redw.all_reduce())
-        b2 = dict(batch)
-        b2["cloth"] = warp.warped_cloth.detach()
-        optu.zero_grad()
-        res = unet.training_step(b2, 0)
-        res.minimize.backward()
-        optu.step(grad_scale=redu.all_reduce())
-
-    # first step: every new layer shape times its (tile, split-K) candidates; keep the streams serial meanwhile so
-    # the measurements are not disturbed by the concurrent weight-gradient stream
-    from shineon_virtual_tryon_amd import ops as so_ops
-
-    concurrent = so_ops.CONCURRENT_WGRAD and not args.serial_wgrad
-    so_ops.CONCURRENT_WGRAD = False
-    eager_step()
-    torch.cuda.synchronize()
-    so_ops.CONCURRENT_WGRAD = concurrent
-    log(f"{L.so_igemm_plan_count()} igemm plans measured; concurrent wgrad stream: {concurrent}")
-
-    step = eager_step
-    if not args.no_graph:
-        # forward+backward of each model captured once as a hipGraph; Adam + RCCL all-reduce stay eager
-        from shineon_virtual_tryon_amd.graphs import GraphedTrainStep
-
-        eager_step()  # allocates workspaces, sets kernel attributes, plants the flat gradient views
-        pending = {"unet": False}
-        gp = gw = gu = None
-        use_pipeline = not args.no_pipeline
-        if use_pipeline and world > 1:
-            # The two-stream schedule hides the warp model's gradient exchange but leaves the try-on model's exposed
-            # between two try-on graphs; the sequential schedule hides both behind the other model's graph.  Measure the
-            # try-on all-reduce on this node (same message sizes, scratch buffer) and keep the two-stream schedule only
-            # where its gain on one GPU (~1.0 ms/step) exceeds that exposure.  All ranks take the same decision (MAX).
-            scratch = torch.zeros_like(optu.flat_grads)
-            probe = GradientAllReducer(scratch)
-            for _ in range(2):
-                probe.all_reduce()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                probe.all_reduce()
-            e1.record()
-            torch.cuda.synchronize()
-            t_ms = torch.tensor([e0.elapsed_time(e1) / 5], dtype=torch.float64, device=dev)
-            dist.all_reduce(t_ms, op=dist.ReduceOp.MAX)
-            use_pipeline = float(t_ms.item()) < 1.0
-            log(f"try-on gradient all-reduce ({scratch.numel() * 4 / 1e6:.1f} MB, {world} ranks): {float(t_ms.item()):.2f} ms -> "
-                f"{'two-stream' if use_pipeline else 'sequential'} schedule")
-            del scratch, probe
-        if use_pipeline:
-            from shineon_virtual_tryon_amd.graphs import GraphedChainedStep
-
-            gp = GraphedChainedStep(warp, optw, unet, optu, batch)
-        else:
-            gw = GraphedTrainStep(warp, optw, batch)
-            b2 = dict(batch)
-            b2["cloth"] = warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
-            gu = GraphedTrainStep(unet, optu, b2, alias_keys=("cloth",))
-
-        def flush():
-            if pending["unet"]:
-                optu.step(grad_scale=redu.finish())
-                pending["unet"] = False
-
-        def step_pipeline():
-            # side stream: warp fwd -> warp bwd -> warp all-reduce -> warp Adam, all behind the try-on graph;
-            # main stream: (previous try-on all-reduce, Adam) -> try-on fwd+bwd -> try-on all-reduce (hidden behind the
-            # next step's warp forward).  The try-on stage only waits for the warped cloth.
-            gp.launch_warp_forward()
-            flush()
-            gp.launch_tryon()
-            gp.launch_warp_backward()
-            with gp.on_side():
-                redw.start()
-                optw.step(grad_scale=redw.finish())
-            redu.start()
-            pending["unet"] = True
-
-        def step():
-            if gp is not None:
-                return step_pipeline()
-            # Both all-reduces are hidden behind compute: the warp gradients travel over xGMI while the try-on
-            # graph runs, the try-on gradients while the NEXT step's warp graph runs (the two models share no
-            # parameters, so the try-on Adam update only has to land before the next try-on forward).
-            gw()
-            redw.start()
-            flush()
-            gu()
-            redu.start()
-            pending["unet"] = True
-            optw.step(grad_scale=redw.finish())
+    if cfg == "c4":
+        schedule = "eager" if args.no_graph else ("sequential" if args.no_pipeline else "auto")
+        engine = trainer.build_chained_step(warp, unet, batch, schedule=schedule, log=log)
+        step, flush, launch = (lambda: engine()), engine.flush, engine.launch_description
+        eager_step = lambda: engine.eager_step()  # noqa: E731
+        join = engine.synchronize
+    else:
+        model = warp if cfg == "c2" else unet
+        (opt,), _ = model.configure_optimizers()
+        broadcast_parameters(model, optimizer=opt)
+        engine = TrainStep(model, opt, batch, graph=not args.no_graph, overlap=True)
+        step, flush = (lambda: engine(batch)), engine.flush
+        launch = "eager" if args.no_graph else "one hipGraph (forward+backward); Adam and all-reduce eager"
+        eager_step = lambda: (engine.flush(), engine._eager(batch), engine.flush())  # noqa: E731
+        join = lambda: (engine.flush(), torch.cuda.synchronize())  # noqa: E731
+    log(f"{L.so_igemm_plan_count()} igemm plans in use")
+    if world > 1:
+        log(f"rank {rank}/{world}: backend {dist.get_backend()}, NCCL_ALGO={os.environ.get('NCCL_ALGO', 'default')}, "
+            f"gradient slabs " + ", ".join(f"{o.flat_grads.numel() * 4 / 1e6:.1f} MB" for o in
+                                           ([engine.optw, engine.optu] if cfg == "c4" else [opt])) + " in 4 buckets each")
 
     log(f"rank {rank}/{world}: models built, warm-up {args.warmup} steps")
     for i in range(args.warmup):
@@ -250,8 +257,7 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t_w):.1f} ms")
-    if not args.no_graph:
-        flush()  # the timed region starts with no update pending
+    flush()  # the timed region starts with no update pending
 
     def fence():
         torch.cuda.synchronize()
@@ -265,8 +271,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if not args.no_graph:
-        flush()  # the last try-on Adam update belongs to the timed steps
+    flush()  # the last Adam update belongs to the timed steps
     fence()
     elapsed = time.perf_counter() - t0
     L.so_prof_enable(0)
@@ -276,6 +281,7 @@ def main():
         # Kernels inside a replayed graph cannot be bracketed individually, so the per-kernel HIP-event timing
         # (roofline figure) is taken on the SAME kernels launched eagerly right after the timed region.
         prof_steps = min(args.steps, 5)
+        join()
         eager_step()
         fence()
         L.so_prof_enable(1)
@@ -299,11 +305,13 @@ def main():
                    for k in range(32) if cnt[k] > 0}
         dom = max(range(32), key=lambda k: ms[k])
         traffic = None  # HBM bytes per launch of the dominant instantiation, from the committed PMC passes
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and cfg == "c4":
             traffic = json.load(open(tpath)).get(KEY_NAMES[dom], {}).get("hbm_bytes_per_launch")
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         mfma_ms = sum(ms) / prof_steps
+        step_ms = 1e3 * elapsed / args.steps
+        step_tflops = GF_PER_FRAME[cfg] * args.batch / step_ms  # GF / ms = TFLOP/s (per GPU: weak scaling)
         out = {
             "metric": "try-on frames/sec (fwd+bwd) at 256x192 bs=4",
             "value": world * args.batch * args.steps / elapsed,
@@ -311,31 +319,38 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "fp32",
             "data": "synthetic",
-            "config": {
-                "workload": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then "
-                            "UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, "
-                            "256x192",
-                "launch": ("eager" if args.no_graph else "two sequential hipGraphs (warp, try-on); Adam and all-reduce eager" if gp is None
-                           else "three hipGraphs on two streams: warp forward -> [try-on fwd+bwd || warp backward + its all-reduce + Adam]; "
-                                "Adam and all-reduce eager"), "batch_per_gpu": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-            },
+            "config": {"workload": WORKLOADS[cfg], "config": cfg, "launch": launch, "batch_per_gpu": args.batch,
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "step_api": "shineon_virtual_tryon_amd.trainer." + ("ChainedTrainStep" if cfg == "c4" else "TrainStep")},
             "roofline": {
                 "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)" if traffic else None, "timing": ("hip events, eager launches in the timed region" if args.no_graph else f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the graph-replayed timed region"), "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
-                "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / (1e3 * elapsed / args.steps),
+                "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "bytes per launch)" if traffic else None,
+                "timing": ("hip events, eager launches in the timed region" if args.no_graph else
+                           f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the "
+                           "graph-replayed timed region"),
+                "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+                "step": {"algorithmic_gflop_per_step": GF_PER_FRAME[cfg] * args.batch, "achieved": step_tflops,
+                         "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS,
+                         "note": "whole step incl. every non-GEMM kernel, Adam and launch gaps: algorithmic FLOPs (SURVEY 8d) / "
+                                 "measured step time / fp32-MFMA peak"},
+                "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / step_ms,
                 "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
             },
             "kernels": kernels,
         }
+        if not args.no_hbm_table:
+            out["roofline"]["hbm"] = {"peak_GB/s": PEAK_HBM_GBS, "kernels": hbm_table(dev, args.batch)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.batch, args.cpu_iters)
         print(json.dumps(out), flush=True)
     if args.plans and rank == 0:
         log(f"saved {L.so_igemm_plans_save(args.plans.encode())} igemm plans to {args.plans}")

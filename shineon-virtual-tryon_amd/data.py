@@ -70,6 +70,8 @@ def synthetic_sample(index, height=256, width=192, n_frames=1, seed=420, radius=
 
 
 class SyntheticDataset(Dataset):
+    device_resident = True  # trainer.Trainer keeps the collated set in HBM and gathers batches on the device
+
     def __init__(self, opt, length=None):
         self.opt = opt
         self.length = length if length is not None else getattr(opt, "synthetic_length", 64)

@@ -8,9 +8,9 @@ from .vgg import Vgg19
 
 
 class VGGLoss(nn.Module):
-    def __init__(self, layids=None, pretrained=True):
+    def __init__(self, layids=None, pretrained=True, weights_file=None):
         super().__init__()
-        self.vgg = Vgg19(pretrained=pretrained)
+        self.vgg = Vgg19(pretrained=pretrained, weights_file=weights_file)
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
         self.layids = layids
 

@@ -29,26 +29,66 @@ def _vgg19_features():
     return layers
 
 
-def _try_load_pretrained(layers):
+def _copy_into(layers, weights_by_index, what):
+    """weights_by_index: {features index: (weight, bias)} in torchvision's vgg19().features numbering."""
+    import torch
+
+    convs = [(i, layer) for i, layer in enumerate(layers) if isinstance(layer, HipConv2d)]
+    missing = [i for i, _ in convs if i not in weights_by_index]
+    if missing:
+        raise KeyError(f"{what}: no weights for VGG19 features layers {missing}")
+    with torch.no_grad():
+        for i, layer in convs:
+            w, b = weights_by_index[i]
+            if tuple(w.shape) != tuple(layer.weight.shape):
+                raise ValueError(f"{what}: features.{i}.weight has shape {tuple(w.shape)}, expected {tuple(layer.weight.shape)}")
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+
+
+def load_vgg19_file(layers, path):
+    """VGG19 weights from a file: either torchvision's vgg19 state_dict layout (`features.<i>.weight/bias`, what
+    `torchvision.models.vgg19(pretrained=True).state_dict()` saves) or any checkpoint / state_dict that carries this
+    model's own `...vgg.slice<k>.<i>.weight/bias` keys (a reference or shineon checkpoint)."""
+    import re
+
+    import torch
+
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+    found = {}
+    for k, v in sd.items():
+        m = re.search(r"(?:^|\.)features\.(\d+)\.(weight|bias)$", k) or re.search(r"vgg\.slice\d\.(\d+)\.(weight|bias)$", k)
+        if m:
+            found.setdefault(int(m.group(1)), {})[m.group(2)] = v
+    _copy_into(layers, {i: (d["weight"], d["bias"]) for i, d in found.items() if "weight" in d and "bias" in d}, path)
+
+
+def _try_load_pretrained(layers, weights_file=None):
+    """ImageNet weights: an explicit file (--vgg_weights) wins; else torchvision's download cache if torchvision is
+    installed (models/networks/vgg.py:9 does vgg19(pretrained=True)).  Returns True when real weights were loaded."""
+    if weights_file:
+        load_vgg19_file(layers, weights_file)  # errors propagate: an explicit request must not fall back silently
+        return True
     try:
         from torchvision import models  # not installed on the build image
 
         feats = models.vgg19(pretrained=True).features
-        for i, layer in enumerate(layers):
-            if isinstance(layer, HipConv2d):
-                layer.weight.data.copy_(feats[i].weight.data)
-                layer.bias.data.copy_(feats[i].bias.data)
+        _copy_into(layers, {i: (m.weight.data, m.bias.data) for i, m in enumerate(feats) if hasattr(m, "weight")},
+                   "torchvision vgg19")
         return True
     except Exception as e:  # noqa: BLE001
-        logger.warning("VGG19 ImageNet weights unavailable (%s); using frozen random weights", type(e).__name__)
+        logger.warning("VGG19 ImageNet weights unavailable (%s); the perceptual loss holds frozen RANDOM weights until "
+                       "--vgg_weights <file> is given (training refuses to start without --allow_random_vgg)",
+                       type(e).__name__)
         return False
 
 
 class Vgg19(nn.Module):
-    def __init__(self, requires_grad=False, pretrained=True):
+    def __init__(self, requires_grad=False, pretrained=True, weights_file=None):
         super().__init__()
         feats = _vgg19_features()
-        self.pretrained_loaded = _try_load_pretrained(feats) if pretrained else False
+        self.pretrained_loaded = _try_load_pretrained(feats, weights_file) if (pretrained or weights_file) else False
         self.slice1, self.slice2, self.slice3 = nn.Sequential(), nn.Sequential(), nn.Sequential()
         self.slice4, self.slice5 = nn.Sequential(), nn.Sequential()
         for lo, hi, sl in ((0, 2, self.slice1), (2, 7, self.slice2), (7, 12, self.slice3), (12, 21, self.slice4),

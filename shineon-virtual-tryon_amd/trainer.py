@@ -1,11 +1,17 @@
 """Lightning-free training / test driver exposing the hooks the reference's Trainer calls
 (reference: train.py:32-141; Lightning 0.9 `Trainer(gpus, distributed_backend="ddp", ...)`).
 
-One process per GPU.  Data parallelism = mean all-reduce of the flat gradient slab over RCCL
-(torch.distributed backend "nccl"), issued in a few large buckets on a side stream so that the
-transfer over xGMI overlaps the remaining work of the step; BatchNorm statistics stay per-rank like the
-reference's nn.BatchNorm2d under DDP, with rank 0's running stats broadcast to mirror DDP's
-broadcast_buffers.
+One process per GPU.  Data parallelism = mean all-reduce of the flat gradient slab over RCCL (torch.distributed
+backend "nccl"), a few large buckets, issued asynchronously so the transfer over xGMI overlaps whatever the step still
+has to do; BatchNorm statistics stay per rank like the reference's nn.BatchNorm2d under DDP, with rank 0's running
+statistics broadcast once per step as ONE flat tensor (DDP's broadcast_buffers).
+
+The step itself lives in two small engines that bench.py and Trainer.fit share:
+  TrainStep         one model: forward+backward as a replayed hipGraph (graph=True), asynchronous gradient exchange,
+                    fused Adam; the exchange + Adam of step i are completed right before step i+1's graph is launched
+                    (overlap=True), i.e. they overlap the host-side batch preparation of step i+1.
+  ChainedTrainStep  the warp -> try-on pair of SURVEY 8d C4: three hipGraphs on two streams (graphs.GraphedChainedStep) or two
+                    sequential graphs, both gradient exchanges hidden behind the other model's compute.
 """
 import logging
 import os
@@ -32,6 +38,10 @@ def init_distributed(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class GradientAllReducer:
     """Mean all-reduce of a flat gradient slab in `n_buckets` contiguous pieces.
 
@@ -46,7 +56,6 @@ class GradientAllReducer:
         step = (step + 1023) // 1024 * 1024
         self.buckets = [flat_grads[i:min(i + step, n)] for i in range(0, n, step)]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-
         self._works = None
 
     def start(self):
@@ -72,30 +81,344 @@ class GradientAllReducer:
         return self.finish()
 
 
-def broadcast_buffers(model, src=0):
-    """DDP's broadcast_buffers=True: rank 0's BatchNorm running stats win."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    for b in model.buffers():
-        dist.broadcast(b, src)
+# ---- buffers / parameters: ONE collective each ------------------------------------------------------------------------
+def flatten_float_buffers(model):
+    """Re-home every floating-point buffer of `model` (BatchNorm running_mean / running_var) as a view of ONE flat tensor
+    and return it (None if there are none).  state_dict keys, shapes and values are unchanged; kernels keep writing the
+    running statistics through the views.  Idempotent while the buffers have not been moved (model.to())."""
+    cached = getattr(model, "_so_flat_buffers", None)
+    entries = [(m, name, b) for m in model.modules() for name, b in m._buffers.items()
+               if b is not None and b.is_floating_point()]
+    if not entries:
+        return None
+    if cached is not None and all(b.device == cached.device and b.data_ptr() >= cached.data_ptr() and
+                                  b.data_ptr() < cached.data_ptr() + cached.numel() * 4 for _, _, b in entries):
+        return cached
+    sizes = [(b.numel() + 3) // 4 * 4 for _, _, b in entries]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=entries[0][2].device)
+    off = 0
+    for (m, name, b), sz in zip(entries, sizes):
+        view = flat[off:off + b.numel()].view(b.shape)
+        view.copy_(b)
+        m._buffers[name] = view
+        off += sz
+    object.__setattr__(model, "_so_flat_buffers", flat)
+    return flat
 
 
-def broadcast_parameters(model, src=0):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_buffers(model, src=0, async_op=False):
+    """DDP's broadcast_buffers=True: rank 0's BatchNorm running statistics win - one collective over the flat buffer
+    tensor.  (num_batches_tracked is advanced identically on every rank, so the integer counters need no exchange.)"""
+    if _world() == 1:
+        return None
+    flat = flatten_float_buffers(model)
+    if flat is None:
+        return None
+    return dist.broadcast(flat, src, async_op=async_op)
+
+
+def broadcast_parameters(model, src=0, optimizer=None):
+    """Rank 0's initial weights everywhere (DDP's constructor broadcast).  With the optimizer given, the whole flat
+    parameter slab travels as one message; otherwise one message per parameter."""
+    if _world() == 1:
         return
-    for p in model.parameters():
-        dist.broadcast(p.data, src)
+    if optimizer is not None:
+        dist.broadcast(optimizer.flat_params, src)
+    else:
+        for p in model.parameters():
+            dist.broadcast(p.data, src)
+    broadcast_buffers(model, src)
+
+
+class _BufferSnapshot:
+    """Engine construction runs the model a few times without an optimizer step (plan measurement, graph warm-up): those
+    passes must not leave a trace in BatchNorm's running statistics / batch counters.  Values are put back IN PLACE (the
+    buffers may be views of flat tensors that kernels and graphs hold by address)."""
+
+    def __init__(self, *models):
+        for m in models:  # buffers get their final home first (flat float tensor, shared BatchNorm counters)
+            flatten_float_buffers(m)
+            if hasattr(m, "plant_shared_buffers"):
+                m.plant_shared_buffers()
+        self.saved = [(b, b.detach().clone()) for m in models for b in m.buffers()]
+
+    def restore(self):
+        with torch.no_grad():
+            for b, v in self.saved:
+                b.copy_(v)
 
 
 def _to_device(batch, device):
     return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 
+# ---- step engines ------------------------------------------------------------------------------------------------------
+class TrainStep:
+    """One optimisation step of one model: (load batch ->) forward + backward -> gradient exchange -> Adam."""
+
+    def __init__(self, model, optimizer, sample_batch, graph=True, overlap=True, accumulate=1, sync_buffers=True):
+        self.model, self.optimizer = model, optimizer
+        self.accumulate = max(1, int(accumulate))
+        self.graph = bool(graph) and self.accumulate == 1   # gradient accumulation re-enters backward: eager only
+        self.overlap = bool(overlap)
+        self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(model) is not None
+        optimizer.zero_grad()
+        self.reducer = GradientAllReducer(optimizer.flat_grads)
+        self._pending = False
+        self._micro = 0
+        self._graphed = None
+        self._shapes = {k: tuple(v.shape) for k, v in sample_batch.items() if isinstance(v, torch.Tensor)}
+        if self.graph:
+            from .graphs import GraphedTrainStep
+
+            snap = _BufferSnapshot(model)
+            self._eager(sample_batch, update=False)  # measures igemm plans, sizes every scratch slab before the capture
+            self._graphed = GraphedTrainStep(model, optimizer, sample_batch)
+            torch.cuda.synchronize()
+            snap.restore()
+
+    def _fits(self, batch):
+        return all(tuple(batch[k].shape) == s for k, s in self._shapes.items() if k in batch)
+
+    def _eager(self, batch, update=True):
+        if self._micro == 0:
+            self.optimizer.zero_grad()
+        res = self.model.training_step(batch, 0)
+        (res.minimize / self.accumulate if self.accumulate > 1 else res.minimize).backward()
+        self._micro += 1
+        if update and self._micro == self.accumulate:
+            self._micro = 0
+            self.reducer.start()
+            self._pending = True
+            if not self.overlap:
+                self.flush()
+        elif not update:
+            self._micro = 0
+        return res
+
+    def flush(self):
+        """Complete the outstanding gradient exchange and apply Adam (no-op if nothing is pending)."""
+        if self._pending:
+            self.optimizer.step(grad_scale=self.reducer.finish())
+            self._pending = False
+
+    @property
+    def stepped(self):
+        """True when the last call completed an accumulation window (an optimizer step was issued or is pending)."""
+        return self._micro == 0
+
+    def __call__(self, batch):
+        self.flush()  # parameters of the previous step must have landed before this forward
+        if self.sync_buffers:
+            broadcast_buffers(self.model)
+        if self._graphed is not None and self._fits(batch):
+            res = self._graphed(batch)
+            self.reducer.start()
+            self._pending = True
+            if not self.overlap:
+                self.flush()
+            return res
+        return self._eager(batch)  # eager mode, or a ragged last batch of the epoch
+
+
+class ChainedTrainStep:
+    """The chained warp -> try-on step (the reference hands the warped cloth over through PNG files,
+    models/warp_model.py:143-149 -> datasets/vvt_dataset.py:139-150; in process it is the detached tensor):
+    WarpModel fwd+bwd+Adam, then UnetMaskModel fwd+bwd+Adam on the warped cloth.
+
+    schedule = "pipeline": three hipGraphs on two streams (graphs.GraphedChainedStep) - side stream: warp forward ->
+        warp backward -> warp gradient exchange -> warp Adam; main stream: try-on fwd+bwd -> its exchange (hidden behind
+        the next step's warp forward) -> try-on Adam.
+    schedule = "sequential": two graphs back to back; the warp exchange hides behind the try-on graph, the try-on
+        exchange behind the next warp graph.
+    schedule = "eager": every kernel launched from Python (profiling / PMC passes).
+    schedule = "auto": "pipeline" on one rank; with several ranks the try-on exchange is timed once on this node and
+        "pipeline" is kept only if it is cheaper than what the two-stream schedule gains (`pipeline_gain_ms`)."""
+
+    def __init__(self, warp, optw, unet, optu, sample_batch, schedule="auto", pipeline_gain_ms=1.0, sync_buffers=True, log=None):
+        self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
+        self.batch = sample_batch
+        optw.zero_grad()
+        optu.zero_grad()
+        self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads)
+        self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(warp) is not None
+        self._pending_u = False
+        self._gp = self._gw = self._gu = None
+        self.exchange_ms = None
+        if schedule == "auto":
+            schedule = "pipeline"
+            if _world() > 1:
+                self.exchange_ms = self._time_exchange(optu.flat_grads)
+                schedule = "pipeline" if self.exchange_ms < pipeline_gain_ms else "sequential"
+                if log:
+                    log(f"try-on gradient all-reduce ({optu.flat_grads.numel() * 4 / 1e6:.1f} MB, {_world()} ranks): "
+                        f"{self.exchange_ms:.2f} ms -> {schedule} schedule")
+        self.schedule = schedule
+        snap = _BufferSnapshot(warp, unet)
+        if schedule != "eager":
+            self.eager_step(sample_batch, update=False)  # plans measured, scratch slabs sized, gradient views planted
+        if schedule == "pipeline":
+            from .graphs import GraphedChainedStep
+
+            self._gp = GraphedChainedStep(warp, optw, unet, optu, sample_batch)
+        elif schedule == "sequential":
+            from .graphs import GraphedTrainStep
+
+            self._gw = GraphedTrainStep(warp, optw, sample_batch)
+            b2 = dict(sample_batch)
+            b2["cloth"] = warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
+            self._gu = GraphedTrainStep(unet, optu, b2, alias_keys=("cloth",))
+        elif schedule != "eager":
+            raise ValueError(f"unknown schedule {schedule!r}")
+        torch.cuda.synchronize()
+        snap.restore()
+
+    @staticmethod
+    def _time_exchange(flat, reps=5):
+        """All-reduce time of a slab of this size on this node (scratch copy; MAX over ranks so all take one decision)."""
+        scratch = torch.zeros_like(flat)
+        probe = GradientAllReducer(scratch)
+        for _ in range(2):
+            probe.all_reduce()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            probe.all_reduce()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    @property
+    def launch_description(self):
+        return {"eager": "eager",
+                "sequential": "two sequential hipGraphs (warp, try-on); Adam and all-reduce eager",
+                "pipeline": "three hipGraphs on two streams: warp forward -> [try-on fwd+bwd || warp backward + its "
+                            "all-reduce + Adam]; Adam and all-reduce eager"}[self.schedule]
+
+    def eager_step(self, batch=None, update=True):
+        batch = self.batch if batch is None else batch
+        self.flush()
+        if self.sync_buffers and update:
+            broadcast_buffers(self.warp)
+        self.optw.zero_grad()
+        rw = self.warp.training_step(batch, 0)
+        rw.minimize.backward()
+        if update:
+            self.optw.step(grad_scale=self.redw.all_reduce())
+        b2 = dict(batch)
+        b2["cloth"] = self.warp.warped_cloth.detach()
+        self.optu.zero_grad()
+        ru = self.unet.training_step(b2, 0)
+        ru.minimize.backward()
+        if update:
+            self.optu.step(grad_scale=self.redu.all_reduce())
+        return rw, ru
+
+    def flush(self):
+        """Land the try-on update that is still travelling (its exchange overlaps the next step's warp forward)."""
+        if self._pending_u:
+            self.optu.step(grad_scale=self.redu.finish())
+            self._pending_u = False
+
+    def __call__(self, batch=None):
+        """One chained step; `batch` (device tensors of the captured shapes) is copied into the static buffers, None
+        re-uses the resident batch.  Results are device tensors valid after the streams are synchronised."""
+        if self.schedule == "eager":
+            return self.eager_step(batch)
+        gp = self._gp
+        if gp is not None:
+            if self.sync_buffers:
+                with gp.on_side():
+                    broadcast_buffers(self.warp)
+            gp.launch_warp_forward(batch)
+            self.flush()
+            gp.launch_tryon(batch)
+            gp.launch_warp_backward()
+            with gp.on_side():
+                self.redw.start()
+                self.optw.step(grad_scale=self.redw.finish())
+            self.redu.start()
+            self._pending_u = True
+            return gp.result_warp, gp.result_tryon
+        if self.sync_buffers:
+            broadcast_buffers(self.warp)
+        rw = self._gw(batch)
+        self.redw.start()
+        self.flush()
+        if batch is not None:
+            self._gu.load_batch({k: v for k, v in batch.items() if k != "cloth"})
+        ru = self._gu()
+        self.redu.start()
+        self._pending_u = True
+        self.optw.step(grad_scale=self.redw.finish())
+        return rw, ru
+
+    def synchronize(self):
+        self.flush()
+        if self._gp is not None:
+            self._gp.join()
+        torch.cuda.synchronize()
+
+
+# ---- data: the dataset resident in HBM ----------------------------------------------------------------------------------
+class DeviceBatches:
+    """A map-style dataset collated ONCE and kept resident in HBM (288 GB: the synthetic VVT-shaped set is 9.4 MB per
+    sample); batches are gathered by index on the device, so the input side costs one small kernel per batch key instead
+    of a per-sample CPU pipeline.  Rank r of w takes indices r::w of the (optionally shuffled) epoch order, like
+    DistributedSampler (base_model.py:113-121)."""
+
+    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, limit=None):
+        from torch.utils.data.dataloader import default_collate
+
+        n = len(dataset) if limit is None else min(len(dataset), limit)
+        full = default_collate([dataset[i] for i in range(n)])
+        self.tensors = {k: v.to(device) for k, v in full.items() if isinstance(v, torch.Tensor)}
+        self.other = {k: v for k, v in full.items() if not isinstance(v, torch.Tensor)}
+        self.n, self.batch_size, self.device, self.shuffle, self.seed = n, batch_size, device, shuffle, seed
+        self.rank = dist.get_rank() if _world() > 1 else 0
+        self.world = _world()
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        per_rank = (self.n + self.world - 1) // self.world
+        return (per_rank + self.batch_size - 1) // self.batch_size
+
+    def _select_strings(self, v, idx):
+        if isinstance(v, (list, tuple)) and v and isinstance(v[0], (list, tuple)):
+            return [self._select_strings(x, idx) for x in v]
+        if isinstance(v, (list, tuple)) and len(v) == self.n:
+            return [v[i] for i in idx]
+        return v
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        order = torch.randperm(self.n, generator=g) if self.shuffle else torch.arange(self.n)
+        if self.world > 1:  # pad to a multiple of the world size like DistributedSampler, then stride
+            pad = (-self.n) % self.world
+            order = torch.cat([order, order[:pad]])[self.rank::self.world]
+        for i in range(0, len(order), self.batch_size):
+            idx = order[i:i + self.batch_size]
+            didx = idx.to(self.device)
+            batch = {k: v.index_select(0, didx) for k, v in self.tensors.items()}
+            batch.update({k: self._select_strings(v, idx.tolist()) for k, v in self.other.items()})
+            yield batch
+
+
 class Trainer:
     def __init__(self, gpus=None, distributed_backend="ddp", precision=32, default_root_dir="experiments",
                  accumulate_grad_batches=1, max_epochs=10, val_check_interval=1.0, limit_train_batches=1.0,
                  limit_val_batches=1.0, fast_dev_run=False, save_count=10000, resume_from_checkpoint=None,
-                 broadcast_bn_buffers=True, **_):
+                 broadcast_bn_buffers=True, graph=True, overlap=True, device_dataset="auto", **_):
+        """graph: replay forward+backward as a hipGraph (static shapes; a ragged last batch runs eagerly).
+        overlap: leave the gradient exchange + Adam of step i in flight until step i+1 is about to launch.
+        device_dataset: keep the collated dataset resident in HBM ("auto": when the dataset asks for it through a
+        `device_resident = True` attribute, as the synthetic one does)."""
         self.rank, self.world = init_distributed()
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         if self.device is None:
@@ -109,34 +432,74 @@ class Trainer:
         self.save_count = save_count
         self.resume = resume_from_checkpoint
         self.broadcast_bn_buffers = broadcast_bn_buffers
+        self.graph, self.overlap, self.device_dataset = graph, overlap, device_dataset
         self.global_step = 0
         self.current_epoch = 0
         self.model = self.optimizer = self.scheduler = None
+        self._interrupted = False
 
     # ---- checkpoints (Lightning-style dict so reference checkpoints' state_dict drops in) --------------
-    def save_checkpoint(self, path):
+    def save_checkpoint(self, path, epoch_finished=False):
+        """`epoch` is the epoch a resumed run starts with: the current one for a mid-epoch checkpoint, the next one when
+        the epoch has finished (Lightning stores current_epoch + 1)."""
         if self.rank != 0:
             return
+        torch.cuda.synchronize()
         os.makedirs(osp.dirname(path) or ".", exist_ok=True)
+        hp = vars(self.model.hparams)
         torch.save({
             "state_dict": {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
-            "hparams": vars(self.model.hparams),
+            "hparams": hp, "hyper_parameters": hp,
             "optimizer_states": [self.optimizer.state_dict()] if self.optimizer else [],
-            "global_step": self.global_step, "epoch": self.current_epoch,
+            "lr_schedulers": [self.scheduler.state_dict()] if self.scheduler else [],
+            "global_step": self.global_step, "epoch": self.current_epoch + (1 if epoch_finished else 0),
+            "vgg_pretrained": _vgg_flag(self.model),
         }, path)
 
     def _maybe_resume(self):
+        """Weights, optimizer moments, LR schedule position and counters all come back (train.py:39-54: the reference hands
+        the same file to load_from_checkpoint and to resume_from_checkpoint)."""
         if not self.resume:
             return
         ckpt = torch.load(self.resume, map_location="cpu", weights_only=False)
-        self.global_step = ckpt.get("global_step", 0)
-        self.current_epoch = ckpt.get("epoch", 0)
+        self.model.load_state_dict(ckpt["state_dict"], strict=True)
+        vgg = getattr(getattr(self.model, "criterionVGG", None), "vgg", None)
+        if vgg is not None and any(k.startswith("criterionVGG.") for k in ckpt["state_dict"]):
+            # the VGG weights now are the checkpoint's: pretrained unless the checkpoint says it was trained on random ones
+            # (reference checkpoints carry no flag and always hold ImageNet weights, models/networks/vgg.py:9)
+            vgg.pretrained_loaded = bool(ckpt.get("vgg_pretrained", True))
+        self.global_step = int(ckpt.get("global_step", 0))
+        self.current_epoch = int(ckpt.get("epoch", 0))
         if ckpt.get("optimizer_states") and self.optimizer is not None:
             self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        if self.scheduler is not None:
+            if ckpt.get("lr_schedulers"):
+                self.scheduler.load_state_dict(dict(ckpt["lr_schedulers"][0]))
+            else:  # older checkpoint: put the schedule at the epoch we resume with
+                self.scheduler.last_epoch = self.current_epoch
+            for group, lam, base in zip(self.optimizer.param_groups, self.scheduler.lr_lambdas, self.scheduler.base_lrs):
+                group["lr"] = base * lam(self.scheduler.last_epoch)
+            self.scheduler._last_lr = [g["lr"] for g in self.optimizer.param_groups]
 
     def _limit(self, n, lim):
         lim = str2num(str(lim))
         return min(n, lim) if isinstance(lim, int) else max(1, int(n * lim))
+
+    def _loaders(self, model):
+        want = self.device_dataset
+        ds = getattr(model, "train_dataset", None)
+        if want == "auto":
+            want = bool(getattr(ds, "device_resident", False))
+        if not want:
+            return model.train_dataloader(), model.val_dataloader()
+        hp = model.hparams
+        shuffle = not getattr(hp, "no_shuffle", False)
+        return (DeviceBatches(model.train_dataset, hp.batch_size, self.device, shuffle=shuffle),
+                DeviceBatches(model.val_dataset, hp.batch_size, self.device, shuffle=False))
+
+    def _on_sigint(self, *_):
+        # only set a flag: the checkpoint is written at the next step boundary, after the streams have drained
+        self._interrupted = True
 
     # ---- fit ------------------------------------------------------------------------------------------
     def fit(self, model):
@@ -144,46 +507,88 @@ class Trainer:
         model.trainer = self
         model.prepare_data()
         model.setup("fit")
-        broadcast_parameters(model)
         (self.optimizer,), (self.scheduler,) = model.configure_optimizers()
         self._maybe_resume()
-        reducer = GradientAllReducer(self.optimizer.flat_grads)
-        train_loader, val_loader = model.train_dataloader(), model.val_dataloader()
+        if hasattr(model, "require_pretrained_vgg"):
+            model.require_pretrained_vgg()  # after the resume: a checkpoint brings its own criterionVGG.* weights
+        broadcast_parameters(model, optimizer=self.optimizer)
+        train_loader, val_loader = self._loaders(model)
         ckpt_dir = osp.join(self.root, "checkpoints")
-        signal.signal(signal.SIGINT, lambda *a: (self.save_checkpoint(osp.join(ckpt_dir, "interrupted_by_Ctrl-C.ckpt")), exit()))
+        previous = signal.signal(signal.SIGINT, self._on_sigint)
         n_train = self._limit(len(train_loader), self.limit_train_batches)
         vci = str2num(str(self.val_check_interval))
         val_every = vci if isinstance(vci, int) and vci > 0 else max(1, int(n_train * (vci or 1)))
+        step = None
         try:
             for epoch in range(self.current_epoch, self.max_epochs):
                 self.current_epoch = model.current_epoch = epoch
-                if hasattr(train_loader.sampler, "set_epoch"):
-                    train_loader.sampler.set_epoch(epoch)
+                for obj in (train_loader, getattr(train_loader, "sampler", None)):
+                    if hasattr(obj, "set_epoch"):
+                        obj.set_epoch(epoch)
                 model.train()
-                self.optimizer.zero_grad()
                 for i, batch in enumerate(train_loader):
                     if i >= n_train or (self.fast_dev_run and i >= 1):
                         break
-                    if self.broadcast_bn_buffers:
-                        broadcast_buffers(model)
+                    batch = _to_device(batch, self.device)
                     model.global_step = self.global_step
-                    result = model.training_step(_to_device(batch, self.device), i)
-                    (result.minimize / self.accumulate).backward()
-                    if (i + 1) % self.accumulate == 0:
-                        scale = reducer.all_reduce()
-                        self.optimizer.step(grad_scale=scale)
-                        self.optimizer.zero_grad()
+                    if step is None:
+                        step = TrainStep(model, self.optimizer, batch, graph=self.graph, overlap=self.overlap,
+                                         accumulate=self.accumulate, sync_buffers=self.broadcast_bn_buffers)
+                    self.last_result = step(batch)
+                    if step.stepped:
                         self.global_step += 1
                         if self.global_step % self.save_count == 0:
+                            step.flush()
                             self.save_checkpoint(osp.join(ckpt_dir, f"step_{self.global_step:09d}.ckpt"))
+                    if self._interrupted:
+                        step.flush()
+                        self.save_checkpoint(osp.join(ckpt_dir, "interrupted_by_Ctrl-C.ckpt"))
+                        raise KeyboardInterrupt
                     if (i + 1) % val_every == 0:
+                        step.flush()
                         self._validate(model, val_loader)
                         model.train()
+                if step is not None:
+                    step.flush()
                 self.scheduler.step()
+        except KeyboardInterrupt:
+            raise SystemExit(130)
         except Exception as e:  # mirror train.py:63-66: checkpoint, then re-raise
+            torch.cuda.synchronize()
             self.save_checkpoint(osp.join(ckpt_dir, f"interrupted_by_{type(e).__name__}.ckpt"))
             raise
-        self.save_checkpoint(osp.join(ckpt_dir, "final.ckpt"))
+        finally:
+            signal.signal(signal.SIGINT, previous)
+        self.save_checkpoint(osp.join(ckpt_dir, "final.ckpt"), epoch_finished=True)
+
+    def build_chained_step(self, warp, unet, sample_batch, schedule="auto", log=None):
+        """The chained warp -> try-on engine on this trainer's device: optimizers built, rank 0's weights broadcast.
+        This is what bench.py times."""
+        warp, unet = warp.to(self.device).train(), unet.to(self.device).train()
+        (optw,), _ = warp.configure_optimizers()
+        (optu,), _ = unet.configure_optimizers()
+        broadcast_parameters(warp, optimizer=optw)
+        broadcast_parameters(unet, optimizer=optu)
+        schedule = schedule if self.graph or schedule == "eager" else "eager"
+        return ChainedTrainStep(warp, optw, unet, optu, sample_batch, schedule=schedule,
+                                sync_buffers=self.broadcast_bn_buffers, log=log)
+
+    def fit_chained(self, warp, unet, batches, steps):
+        """Train both stages in lockstep on `batches` (an iterable of device batches of one fixed shape) for `steps`
+        chained steps: the C4 workload through the product API.  Returns the engine (losses: engine results)."""
+        engine = None
+        done = 0
+        while done < steps:
+            for batch in batches:
+                if engine is None:
+                    engine = self.build_chained_step(warp, unet, batch)
+                engine(batch)
+                done += 1
+                self.global_step += 1
+                if done >= steps:
+                    break
+        engine.synchronize()
+        return engine
 
     @torch.no_grad()
     def _validate(self, model, loader):
@@ -209,3 +614,8 @@ class Trainer:
         for i, batch in enumerate(model.test_dataloader()):
             outs.append(model.test_step(_to_device(batch, self.device), i))
         return outs
+
+
+def _vgg_flag(model):
+    crit = getattr(model, "criterionVGG", None)
+    return bool(getattr(getattr(crit, "vgg", None), "pretrained_loaded", False)) if crit is not None else None

@@ -40,6 +40,10 @@ class UnetMaskModel(BaseModel):
         parser = super(UnetMaskModel, cls).modify_commandline_options(parser, is_train)
         parser.set_defaults(person_inputs=("agnostic", "densepose"))
         parser.add_argument("--pen_flow_mask", type=float, default=1.0, help="Penalty applied to flow mask loss")
+        parser.add_argument("--vgg_weights", default=None, help="file with ImageNet VGG19 weights for the perceptual loss: "
+                            "torchvision's vgg19 state_dict (features.N.weight/bias) or a checkpoint holding criterionVGG.*")
+        parser.add_argument("--allow_random_vgg", action="store_true", help="train even though no pretrained VGG19 weights "
+                            "could be loaded (synthetic benchmarks / tests only: the perceptual term is then meaningless)")
         return parser
 
     def __init__(self, hparams):
@@ -59,8 +63,17 @@ class UnetMaskModel(BaseModel):
             activation=hparams.activation,
         )
         self.resample = Resample2d()
-        self.criterionVGG = VGGLoss()
+        self.criterionVGG = VGGLoss(weights_file=getattr(hparams, "vgg_weights", None))
         init_weights(self.unet, init_type="normal")
+
+    def require_pretrained_vgg(self):
+        """Called by Trainer.fit before training starts: the reference always trains against ImageNet VGG19 features
+        (models/networks/vgg.py:9); refuse to optimise against random ones unless explicitly allowed.  A checkpoint
+        loaded afterwards brings its own criterionVGG.* weights (they are part of the state_dict)."""
+        if not self.criterionVGG.vgg.pretrained_loaded and not getattr(self.hparams, "allow_random_vgg", False):
+            raise RuntimeError("UnetMaskModel: no pretrained VGG19 weights for the perceptual loss (torchvision is not "
+                               "installed / offline). Pass --vgg_weights <vgg19 state_dict or checkpoint>, or "
+                               "--allow_random_vgg for synthetic benchmarks and tests.")
 
     def forward(self, person_representation, warped_cloths, flows=None, prev_im=None):
         n = self.hparams.n_frames_total

@@ -40,16 +40,23 @@ class WarpModel(BaseModel):
         self.regression = FeatureRegression(input_nc=192, output_dim=2 * hparams.grid_size ** 2)
         self.gridGen = TpsGridGen(hparams.fine_height, hparams.fine_width, grid_size=hparams.grid_size)
 
-    def _bump_bn_counters(self):
-        """num_batches_tracked += 1 for all 14 BatchNorm layers with one launch (layers.share_bn_counters)."""
+    def plant_shared_buffers(self):
+        """Re-home the 14 num_batches_tracked counters as views of ONE int64 tensor (layers.share_bn_counters) and
+        return it; idempotent until the buffers are moved by .to()."""
         flat = getattr(self, "_bn_flat", None)
         first = next((m for m in self.modules() if isinstance(m, HipBatchNorm2d)), None)
         if first is None:
-            return
+            return None
         if flat is None or first.num_batches_tracked.data_ptr() != flat.data_ptr():  # first use, or moved by .to()
             flat = share_bn_counters(self)
             object.__setattr__(self, "_bn_flat", flat)
-        flat.add_(1)
+        return flat
+
+    def _bump_bn_counters(self):
+        """num_batches_tracked += 1 for all 14 BatchNorm layers with one launch."""
+        flat = self.plant_shared_buffers()
+        if flat is not None:
+            flat.add_(1)
 
     def forward(self, inputA, inputB):
         if self.training:

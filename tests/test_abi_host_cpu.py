@@ -210,6 +210,31 @@ idx = list(DistributedSampler(list(range(10)), shuffle=False))
 got = [torch.zeros(5, dtype=torch.long) for _ in range(2)]
 dist.all_gather(got, torch.tensor(idx))
 assert sorted(torch.cat(got).tolist()) == list(range(10))
+# BatchNorm buffers travel as ONE flat tensor; state_dict keys / shapes unchanged; rank 0 wins
+from shineon_virtual_tryon_amd.trainer import DeviceBatches, broadcast_buffers, flatten_float_buffers
+net = torch.nn.Sequential(torch.nn.BatchNorm2d(3), torch.nn.Conv2d(3, 3, 1), torch.nn.BatchNorm2d(5))
+keys = list(net.state_dict().keys())
+for m in net:
+    if hasattr(m, "running_mean"):
+        m.running_mean.fill_(float(rank + 1)); m.running_var.fill_(float(10 * (rank + 1)))
+flat = flatten_float_buffers(net)
+assert flat.numel() == 4 + 4 + 8 + 8 and flatten_float_buffers(net) is flat
+assert list(net.state_dict().keys()) == keys and net[2].running_var.shape == (5,)
+broadcast_buffers(net)
+assert float(net[0].running_mean[0]) == 1.0 and float(net[2].running_var[4]) == 10.0
+net[0](torch.randn(4, 3, 2, 2))          # training forward still updates the (re-homed) running statistics in place
+assert float(flat[0]) != 1.0
+# the HBM-resident batch loader strides the epoch order like DistributedSampler: disjoint, covering, same length per rank
+class _DS(torch.utils.data.Dataset):
+    def __len__(self): return 10
+    def __getitem__(self, i): return {"x": torch.full((2,), float(i)), "name": [f"n{i}"]}
+seen = []
+for b in DeviceBatches(_DS(), 2, torch.device("cpu"), shuffle=True, seed=3):
+    assert len(b["name"][0]) == b["x"].shape[0] and b["name"][0][0] == f"n{int(b['x'][0, 0])}"
+    seen += b["x"][:, 0].long().tolist()
+got = [torch.zeros(5, dtype=torch.long) for _ in range(2)]
+dist.all_gather(got, torch.tensor(seen))
+assert sorted(torch.cat(got).tolist()) == list(range(10))
 dist.barrier()
 print("DP_OK", rank)
 """

@@ -423,12 +423,31 @@ def test_trainer_fit_resume_and_test(cuda, tmp_path):
     assert int(saved["state_dict"]["extractionA.model.2.num_batches_tracked"]) == 3  # training forwards only (shared counter)
     assert saved["optimizer_states"][0]["steps"] == 3
 
-    # resume: optimizer moments and step counters come back from the checkpoint
+    # resume: weights, Adam moments, step counters AND the LR-schedule position come back from the checkpoint alone
+    # (no manual load_state_dict: train.py:39-54 hands the same file to load_from_checkpoint and resume_from_checkpoint)
+    assert saved["epoch"] == 1 and saved["lr_schedulers"][0]["last_epoch"] == 1   # end of epoch 0 -> resume starts epoch 1
+    torch.manual_seed(1234)                                                        # different random init: must be overwritten
     model2 = find_model_using_name(opt.model)(opt)
-    model2.load_state_dict(saved["state_dict"], strict=True)
-    t2 = Trainer(default_root_dir=root, max_epochs=1, limit_train_batches=1, limit_val_batches=1, resume_from_checkpoint=ckpt)
+    t2 = Trainer(default_root_dir=root, max_epochs=2, limit_train_batches=1, limit_val_batches=1, resume_from_checkpoint=ckpt)
     t2.fit(model2)
-    assert t2.global_step == 4 and t2.optimizer._steps == 4
+    assert t2.global_step == 4 and t2.optimizer._steps == 4 and t2.current_epoch == 1
+    # one resumed step from the saved weights: every tensor that did not train in that step is still the checkpoint's
+    assert torch.equal(model2.state_dict()["extractionA.model.2.num_batches_tracked"].cpu(), torch.tensor(4))
+    d = (model2.state_dict()[w].cpu() - saved["state_dict"][w]).abs().max()
+    assert 0 < float(d) < 1e-2, float(d)                                           # moved by ~lr from the CHECKPOINT's weights
+    # LR schedule: keep_epochs=5 -> factor 1 through epoch 5; push the epoch counter into the decay phase and resume again
+    saved2 = torch.load(os.path.join(root, "checkpoints", "final.ckpt"), map_location="cpu", weights_only=False)
+    assert saved2["epoch"] == 2
+    saved2["epoch"] = 7
+    saved2["lr_schedulers"][0]["last_epoch"] = 7
+    late = os.path.join(root, "checkpoints", "late.ckpt")
+    torch.save(saved2, late)
+    model4 = find_model_using_name(opt.model)(opt)
+    t4 = Trainer(default_root_dir=root, max_epochs=8, limit_train_batches=1, limit_val_batches=1, resume_from_checkpoint=late)
+    t4.fit(model4)
+    # epoch 7 ran with lr0 * (1 - (7 - 5) / 6), then the scheduler stepped to epoch 8: lr0 * (1 - 3 / 6)
+    assert abs(t4.optimizer.param_groups[0]["lr"] - 1e-3 * (1 - 3 / 6)) < 1e-12, t4.optimizer.param_groups[0]["lr"]
+    assert t4.current_epoch == 7 and t4.global_step == 5
 
     # test: PNG writers under result_dir/name/<ckpt>/<datamode>/<Dataset>/
     topt = TestOptions().parse(["--model", "gmm", "--dataset", "synthetic", "--name", "t", "-b", "2", "--workers", "0",
@@ -455,7 +474,7 @@ def test_trainer_tryon_stage_fit_and_test(cuda, tmp_path):
 
     root = str(tmp_path / "exp")
     common = ["--model", "tom", "--dataset", "synthetic", "--name", "u", "-b", "2", "--workers", "0", "--self_attn", "--activation",
-              "gelu", "--person_inputs", "agnostic", "densepose"]
+              "gelu", "--person_inputs", "agnostic", "densepose", "--allow_random_vgg"]
     opt = TrainOptions().parse(common + ["--synthetic_length", "4", "--experiments_dir", root], interactive=False)
     model = find_model_using_name(opt.model)(opt)
     tr = Trainer(default_root_dir=root, max_epochs=1, limit_train_batches=1, limit_val_batches=1)
@@ -473,3 +492,67 @@ def test_trainer_tryon_stage_fit_and_test(cuda, tmp_path):
     assert len(outs) == 1
     pngs = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path / "res")) for f in fs if f.endswith((".png", ".jpg"))]
     assert len(pngs) >= 2 and all(("tryon" in q) or ("reconstruction" in q) for q in pngs), pngs[:4]
+
+
+def test_vgg_weights_option_and_refusal_to_train_on_random_vgg(cuda, tmp_path):
+    """--vgg_weights loads a torchvision-layout vgg19 state_dict (features.N.weight/bias) or a checkpoint's criterionVGG.*;
+    without pretrained weights Trainer.fit refuses to start unless --allow_random_vgg is given
+    (the reference always trains against ImageNet VGG19: models/networks/vgg.py:9)."""
+    from shineon_virtual_tryon_amd.options import TrainOptions
+    from shineon_virtual_tryon_amd.registry import find_model_using_name
+    from shineon_virtual_tryon_amd.trainer import Trainer
+
+    common = ["--model", "tom", "--dataset", "synthetic", "--name", "v", "-b", "2", "--workers", "0", "--synthetic_length", "2",
+              "--experiments_dir", str(tmp_path)]
+    model = find_model_using_name("tom")(TrainOptions().parse(common, interactive=False))
+    assert not model.criterionVGG.vgg.pretrained_loaded
+    with pytest.raises(RuntimeError, match="vgg_weights"):
+        Trainer(default_root_dir=str(tmp_path), max_epochs=1, limit_train_batches=1).fit(model)
+    # a torchvision-layout file
+    gen = torch.Generator().manual_seed(8)
+    tv = {}
+    for key, v in model.criterionVGG.vgg.state_dict().items():      # slice<k>.<i>.weight -> features.<i>.weight
+        i, leaf = key.split(".")[1:]
+        tv[f"features.{i}.{leaf}"] = torch.randn(v.shape, generator=gen) * 0.05
+    tv["classifier.0.weight"] = torch.zeros(4, 4)                    # ignored
+    path = str(tmp_path / "vgg19.pth")
+    torch.save(tv, path)
+    m2 = find_model_using_name("tom")(TrainOptions().parse(common + ["--vgg_weights", path], interactive=False))
+    assert m2.criterionVGG.vgg.pretrained_loaded
+    for key, v in m2.criterionVGG.vgg.state_dict().items():
+        i, leaf = key.split(".")[1:]
+        assert torch.equal(v.cpu(), tv[f"features.{i}.{leaf}"]), key
+    m2.require_pretrained_vgg()
+    # a checkpoint that carries criterionVGG.* keys
+    ck = str(tmp_path / "ref.ckpt")
+    torch.save({"state_dict": m2.state_dict()}, ck)
+    m3 = find_model_using_name("tom")(TrainOptions().parse(common + ["--vgg_weights", ck], interactive=False))
+    assert torch.equal(getattr(m3.criterionVGG.vgg.slice5, "28").weight, getattr(m2.criterionVGG.vgg.slice5, "28").weight)
+    with pytest.raises(KeyError):
+        bad = {k: v for k, v in tv.items() if not k.startswith("features.28.")}
+        torch.save(bad, path)
+        find_model_using_name("tom")(TrainOptions().parse(common + ["--vgg_weights", path], interactive=False))
+
+
+def test_trainer_graph_overlap_mode_equals_eager_mode(cuda, tmp_path):
+    """Trainer(graph=True, overlap=True) - hipGraph replay, HBM-resident dataset, deferred Adam - trains exactly like the
+    plain eager loop: bit-identical weights after one epoch of 4 steps (+ a ragged last batch that runs eagerly)."""
+    from shineon_virtual_tryon_amd.options import TrainOptions
+    from shineon_virtual_tryon_amd.registry import find_model_using_name
+    from shineon_virtual_tryon_amd.trainer import Trainer
+
+    finals = []
+    for graph in (True, False):
+        root = str(tmp_path / f"g{int(graph)}")
+        opt = TrainOptions().parse(["--model", "gmm", "--dataset", "synthetic", "--name", "t", "-b", "2", "--workers", "0",
+                                    "--synthetic_length", "9", "--experiments_dir", root, "--lr", "1e-3", "--no_shuffle"],
+                                   interactive=False)
+        torch.manual_seed(21)
+        model = find_model_using_name(opt.model)(opt)
+        tr = Trainer(default_root_dir=root, max_epochs=1, limit_val_batches=1, val_check_interval=3, graph=graph, overlap=graph,
+                     device_dataset=graph)
+        tr.fit(model)
+        assert tr.global_step == 5
+        finals.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
