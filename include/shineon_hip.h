@@ -310,6 +310,18 @@ int so_silhouette(const void* shape_u8, float* silhouette, long long stride_out,
  * followed by transforms.Normalize((0.5, 0.5), (0.5, 0.5)). */
 int so_flow_decode(const float* payload, float* flow, int Nb, int HW, void* stream);
 
+/* ---- SAGAN self-attention core, LDS-resident (csrc/attention.hip; sagan.py:44-54) ------------------------------ */
+/* qkv [B*N][E = 2d + C]: columns [0,d) = query, [d,2d) = key, [2d,E) = value projections of x (one engine GEMM).
+ * fwd: attn [B*N][N] = softmax_j(q k^T) (saved for backward), o [B*N][C] = attn v (saved), out = gamma * o + x.
+ * bwd: de [B*N][N] (scratch), dqkv [B*N][E] <- (dq | dk | dv) with dv = gamma * attn^T dout, da = gamma * dout v^T.
+ * Supported when so_attention_supported(N, C, d): N <= 192, C in {128, 256, 384, 512}, d in {32, 64}; otherwise SO_ERR_SHAPE
+ * (the host then uses the GEMM + softmax composition). */
+int so_attention_supported(int N, int C, int d);
+int so_attention_fwd(const float* qkv, int E, int d, const float* x, int ldx, const float* gamma, float* out, int ldo,
+                     float* attn, float* o, int B, int N, int C, void* stream);
+int so_attention_bwd(const float* qkv, int E, int d, const float* dout, int ldg, const float* attn, const float* gamma,
+                     float* de, float* dqkv, int B, int N, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

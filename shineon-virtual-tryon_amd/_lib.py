@@ -81,7 +81,8 @@ def lib():
             fn.restype = restype
             fn.argtypes = argtypes
         # measured (tile, split-K) plans per layer shape; SHINEON_AUTOTUNE=0 falls back to the cost model
-        cdll.so_igemm_autotune(0 if os.environ.get("SHINEON_AUTOTUNE", "1") == "0" else 1)
+        # SHINEON_AUTOTUNE=2: thorough measurement (chip warmed up, 6 timed launches per candidate) for tools/make_plans.py
+        cdll.so_igemm_autotune(int(os.environ.get("SHINEON_AUTOTUNE", "1") or 1))
         global PLANS_LOADED
         plans = os.environ.get("SHINEON_PLANS", PLANS_PATH)
         if plans and plans.lower() != "none" and os.path.exists(plans):

@@ -84,6 +84,12 @@ CONCURRENT_WGRAD = os.environ.get("SHINEON_CONCURRENT_WGRAD", "0") == "1"
 # SHINEON_DGRAD_IN_PLACE=0 goes back to a transposed copy per step (measured 0.05 ms/step slower).  The frozen VGG
 # chain always uses cached transposed weights.
 DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
+# LDS-resident attention core (csrc/attention.hip) for N <= 192, C in {128..512}, d in {32, 64}: one launch forward, two
+# backward, parity-tested (tests/test_models_gpu.py::test_self_attention_lds_resident_core).  Measured on MI355X
+# (tools/attn_bench.py, module fwd+bwd under graph replay, N = 12 / 48 / 192): 107 / 150 / 274 us against 89 / 111 / 152 us for
+# the GEMM + softmax composition - at B = 4 the fused kernels have 16-96 blocks and are latency chains, while the composed
+# path's ~10 us launches already sit near the launch floor.  Hence OFF by default; SHINEON_FUSED_ATTENTION=1 switches it on.
+FUSED_ATTENTION = os.environ.get("SHINEON_FUSED_ATTENTION", "0") == "1"
 
 
 class _SideStream:
@@ -701,14 +707,19 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         qkv = f(b * n, E)
         _gemm(0, 1, b * n, E, c, xp, ldx, 0, wq.data_ptr(), c, 0, qkv.data_ptr(), E, 0, 1, bias=bq.data_ptr(), device=dev)
         qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
-        e = f(b * n, n)
-        _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
-        a = f(b * n, n)
-        check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
-        o = f(b * n, c)
-        _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
+        a, o = f(b * n, n), f(b * n, c)
         out = nhwc_empty(b, h, w, c, dev)
-        check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
+        ctx.core_fused = bool(FUSED_ATTENTION and L.so_attention_supported(n, c, d))
+        if ctx.core_fused:
+            # energy -> softmax -> attention x V -> gamma * o + x in ONE LDS-resident kernel (csrc/attention.hip)
+            check(L.so_attention_fwd(qp, E, d, xp, ldx, gamma.data_ptr(), out.data_ptr(), c, a.data_ptr(), o.data_ptr(),
+                                     b, n, c, _stream()), "attention_fwd")
+        else:
+            e = f(b * n, n)
+            _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
+            check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
+            _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
+            check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
         ctx.save_for_backward(x, qkv, a, o, gamma)
         ctx.params = (wq, bq, gamma)  # first tensors of the adjacent weight / bias runs, and gamma
         return out
@@ -731,14 +742,19 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         gm = gamma.data_ptr()
         qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
         dqkv = f(b * n, E)
-        dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + d * 4, dqkv.data_ptr() + 2 * d * 4
-        _gemm(1, 0, n, c, n, a.data_ptr(), n, n * n, gp, ldg, n * ldg, dvp, E, n * E, b, alpha=gm, device=dev)
-        da = f(b * n, n)
-        _gemm(0, 1, n, n, c, gp, ldg, n * ldg, vp, E, n * E, da.data_ptr(), n, n * n, b, alpha=gm, device=dev)
         de = f(b * n, n)
-        check(L.so_softmax_rows_bwd(a.data_ptr(), n, da.data_ptr(), n, de.data_ptr(), n, b * n, n, _stream()), "softmax_bwd")
-        _gemm(0, 0, n, d, n, de.data_ptr(), n, n * n, kp, E, n * E, dqp, E, n * E, b, device=dev)
-        _gemm(1, 0, n, d, n, de.data_ptr(), n, n * n, qp, E, n * E, dkp, E, n * E, b, device=dev)
+        if ctx.core_fused:
+            # two launches: per 32 queries (da, softmax backward, dq), per 32 keys (dk, dv)
+            check(L.so_attention_bwd(qp, E, d, gp, ldg, a.data_ptr(), gm, de.data_ptr(), dqkv.data_ptr(), b, n, c, _stream()),
+                  "attention_bwd")
+        else:
+            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + d * 4, dqkv.data_ptr() + 2 * d * 4
+            _gemm(1, 0, n, c, n, a.data_ptr(), n, n * n, gp, ldg, n * ldg, dvp, E, n * E, b, alpha=gm, device=dev)
+            da = f(b * n, n)
+            _gemm(0, 1, n, n, c, gp, ldg, n * ldg, vp, E, n * E, da.data_ptr(), n, n * n, b, alpha=gm, device=dev)
+            check(L.so_softmax_rows_bwd(a.data_ptr(), n, da.data_ptr(), n, de.data_ptr(), n, b * n, n, _stream()), "softmax_bwd")
+            _gemm(0, 0, n, d, n, de.data_ptr(), n, n * n, kp, E, n * E, dqp, E, n * E, b, device=dev)
+            _gemm(1, 0, n, d, n, de.data_ptr(), n, n * n, qp, E, n * E, dkp, E, n * E, b, device=dev)
         # dx = dout + [dq | dk | dv] [Wq; Wk; Wv]
         dx = nhwc_empty(b, h, w, c, dev)
         _gemm(0, 0, b * n, c, E, dqkv.data_ptr(), E, 0, wq.data_ptr(), c, 0, dx.data_ptr(), c, 0, 1, res=gp, ldres=ldg, device=dev)
