@@ -112,19 +112,42 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_k(const float* __restric
 }
 
 // ------------------------------------------------------------------ dot product (attention d gamma)
+// d gamma = <dout, o> is a sum of ~4e5 products of either sign that cancels to ~1e-3 of its absolute mass: accumulated
+// in fp32 its round-off is ~10 % of the result.  The products and the sums are therefore carried in fp64 (exact products,
+// fixed summation order); the fp64 pipes are idle on this path anyway.
 __global__ __launch_bounds__(256) void dot_partial_k(const float* __restrict__ a, int lda,
                                                      const float* __restrict__ b, int ldb,
                                                      unsigned rows, unsigned C,
-                                                     float* __restrict__ part) {
-  __shared__ float red[4];
+                                                     double* __restrict__ part) {
+  __shared__ double red[4];
   const unsigned total = rows * C;
-  float s = 0.f;
+  double s = 0.0;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / C, c = idx - row * C;
-    s += a[(size_t)row * lda + c] * b[(size_t)row * ldb + c];
+    s += (double)a[(size_t)row * lda + c] * (double)b[(size_t)row * ldb + c];
   }
-  s = so_block_sum256(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void dot_final_k(const double* __restrict__ part, unsigned n, float scale,
+                                                   float* __restrict__ out, int accumulate) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (unsigned i = threadIdx.x; i < n; i += 256) s += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    out[0] = (accumulate ? out[0] : 0.f) + (float)((double)scale * t);
+  }
 }
 
 __global__ __launch_bounds__(256) void sum_final_k(const float* __restrict__ part, unsigned n,
@@ -560,10 +583,12 @@ int so_dot(const float* a, int lda, const float* b, int ldb, long long rows, int
            float* out, int accumulate, float* ws, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int blocks = grid_for(rows * C);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;  // 512 fp64 partials in the 1024-float scratch
+  if ((((uintptr_t)ws) & 7) != 0) return SO_ERR_ALIGN;
   hipLaunchKernelGGL(dot_partial_k, dim3(blocks), dim3(256), 0, st, a, lda, b, ldb, (unsigned)rows,
-                     (unsigned)C, ws);
-  hipLaunchKernelGGL(sum_final_k, dim3(1), dim3(256), 0, st, ws, (unsigned)blocks, scale, out, accumulate);
+                     (unsigned)C, reinterpret_cast<double*>(ws));
+  hipLaunchKernelGGL(dot_final_k, dim3(1), dim3(256), 0, st, reinterpret_cast<const double*>(ws), (unsigned)blocks, scale,
+                     out, accumulate);
   return SO_LAUNCH_CHECK();
 }
 

@@ -454,6 +454,15 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < BJ; ++j) {
         const int kk = k0 + b_kr * BJ + j;
         if constexpr (MODE == MODE_DGRAD) {
+          if (uni_k) {
+            // Ko % 32 == 0: the whole K tile sits in one class tap (decoded once per tile by load_a, block-uniform);
+            // only the output channel ko = first ko of the tile + this thread's k row differs between threads
+            const int r = d_r0 + p.stride * u_cur_r, s = d_s0 + p.stride * u_cur_s;
+            const int ko = u_cur_c0 + b_kr * BJ + j;
+            const bool ok = (kk < Klim) & (col < p.N);
+            dst[j] = so_bload(rB, ok ? (unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+            continue;
+          }
           // in-place OHWI weights: k row kk = (class tap (tr, ts), ko), carried incrementally like the WGRAD pixel
           const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
