@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="c4: two sequential graphs (warp, then try-on) instead of "
                     "the two-stream schedule that overlaps the warp backward pass with the try-on stage")
     ap.add_argument("--no-hbm-table", action="store_true")
+    ap.add_argument("--vgg-split-bf16", action="store_true", help="NON-HEADLINE experiment: the frozen VGG19 chain of the "
+                    "perceptual loss on the bf16 matrix cores (fp32 = hi + mid bf16 planes, 3 MFMAs per product, fp32 "
+                    "accumulate; csrc/sb16.hip); everything else stays exact fp32.  Reported with its own dtype string.")
     ap.add_argument("--plans", default="", help="extra igemm plans file: loaded on top of the committed one if present, "
                     "and every plan known at the end is written back to it")
     args = ap.parse_args()
@@ -219,6 +222,10 @@ def main():
     if args.plans and os.path.exists(args.plans):
         log(f"loaded {L.so_igemm_plans_load(args.plans.encode())} igemm plans from {args.plans}")
 
+    if args.vgg_split_bf16:
+        from shineon_virtual_tryon_amd import ops as so_ops
+
+        so_ops.VGG_SPLIT_BF16 = True
     torch.manual_seed(420)
     batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch)
     cfg = args.config
@@ -323,7 +330,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32",
+            "dtype": ("fp32" if not args.vgg_split_bf16 else
+                      "fp32; frozen VGG19 chain as 3x bf16-split MFMA (hi*hi + hi*mid + mid*hi, fp32 accumulate) - non-headline"),
             "data": "synthetic",
             "config": {"workload": WORKLOADS[cfg], "config": cfg, "launch": launch, "batch_per_gpu": args.batch,
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",

@@ -322,6 +322,19 @@ int so_attention_fwd(const float* qkv, int E, int d, const float* x, int ldx, co
 int so_attention_bwd(const float* qkv, int E, int d, const float* dout, int ldg, const float* attn, const float* gamma,
                      float* de, float* dqkv, int B, int N, int C, void* stream);
 
+/* ---- split-bf16 3x3 convolution for the frozen VGG19 chain (csrc/sb16.hip; opt-in, non-headline) ----------------- */
+/* fp32 = hi + mid (two bf16 planes); a*b ~= hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ * (vgg.py:6-36 conv3x3 + ReLU; weights are frozen there, vgg.py:25-27, so they are split once).
+ * so_sb16_split: x [rows][ldx] fp32 -> hi / mid planes [rows][C] bf16.
+ * so_sb16_prep_weights: OHWI fp32 [Ko][9][Cw] -> planes [Ko][9][C] (transpose = 0) or the input-gradient weights
+ *   [C][9][Ko] with flipped taps (transpose = 1).
+ * so_sb16_conv3x3: stride 1, pad 1, C % 32 == 0, Ko % 64 == 0; y fp32 [rows][ldy] = act(conv + bias), optional ReLU gate
+ *   (gate [rows][Ko] > 0), optional output planes yh / ym [rows][Ko] for the next convolution. */
+int so_sb16_split(const float* x, int ldx, int C, void* hi, void* mid, long long rows, void* stream);
+int so_sb16_prep_weights(const float* w_ohwi, int Ko, int C, int Cw, int transpose, void* hi, void* mid, void* stream);
+int so_sb16_conv3x3(const void* xh, const void* xm, const void* wh, const void* wm, const float* bias, const float* gate,
+                    float* y, int ldy, void* yh, void* ym, int Nb, int H, int W, int C, int Ko, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

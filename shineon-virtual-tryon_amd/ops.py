@@ -90,6 +90,10 @@ DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
 # the GEMM + softmax composition - at B = 4 the fused kernels have 16-96 blocks and are latency chains, while the composed
 # path's ~10 us launches already sit near the launch floor.  Hence OFF by default; SHINEON_FUSED_ATTENTION=1 switches it on.
 FUSED_ATTENTION = os.environ.get("SHINEON_FUSED_ATTENTION", "0") == "1"
+# Split-bf16 convolutions for the FROZEN VGG19 chain (csrc/sb16.hip): fp32 = hi + mid bf16 planes, three bf16 MFMAs per
+# product instead of one fp32 MFMA stream at 1/16 of the rate.  Not bit-equal to the fp32 path (error ~3x the fp32 MFMA
+# chain's own round-off), so it is OFF by default and reported as its own bench line (bench.py --vgg-split-bf16).
+VGG_SPLIT_BF16 = os.environ.get("SHINEON_VGG_SPLIT_BF16", "0") == "1"
 
 
 class _SideStream:
@@ -1284,6 +1288,41 @@ def tensor_sum(x):
     return _SumFn.apply(x)
 
 
+
+_SB16_W_CACHE = {}
+
+
+def _sb16_eligible(ci, co):
+    return ci % 32 == 0 and co % 64 == 0
+
+
+def _sb16_planes(t2d_ptr, ld, c, rows, device):
+    """fp32 rows -> (hi, mid) bf16 planes [rows][c]."""
+    hi = torch.empty((rows, c), dtype=torch.bfloat16, device=device)
+    mid = torch.empty((rows, c), dtype=torch.bfloat16, device=device)
+    check(lib().so_sb16_split(t2d_ptr, ld, c, hi.data_ptr(), mid.data_ptr(), rows, _stream()), "sb16_split")
+    return hi, mid
+
+
+def _sb16_weights(wk, owner, transpose):
+    """(hi, mid) planes of the frozen OHWI weights `wk` (Ko, 3, 3, C): [Ko][9][C], or for the input gradient [C][9][Ko] with
+    flipped taps.  Cached per parameter object and version like the transposed fp32 copies."""
+    ref, version = owner
+    p = ref()
+    key = (id(p), bool(transpose))
+    hit = _SB16_W_CACHE.get(key) if p is not None else None
+    if hit is not None and hit[0]() is p and hit[1] == version:
+        return hit[2], hit[3]
+    ko, _, _, c = wk.shape
+    hi = torch.empty(ko * 9 * c, dtype=torch.bfloat16, device=wk.device)
+    mid = torch.empty_like(hi)
+    check(lib().so_sb16_prep_weights(wk.data_ptr(), ko, c, c, int(transpose), hi.data_ptr(), mid.data_ptr(), _stream()), "sb16_prep")
+    if p is not None:
+        for k in [k for k, v in _SB16_W_CACHE.items() if v[0]() is None]:
+            del _SB16_W_CACHE[k]
+        _SB16_W_CACHE[key] = (ref, version, hi, mid)
+    return hi, mid
+
 # ------------------------------------------------------------------------------------------------
 # VGG19 perceptual loss as ONE autograd node (models/networks/loss.py:106-122 + vgg.py:6-36)
 # ------------------------------------------------------------------------------------------------
@@ -1319,9 +1358,12 @@ class _VggLossFn(torch.autograd.Function):
         fill_(loss, 0.0)
         cur, saved, meta, pi, ti = inp, [], [], 0, 0
         relu_in = None  # index in `saved` of the ReLU output that is the current tensor (None: image / pooled map)
-        for item in cfg:
+        split = VGG_SPLIT_BF16
+        planes = None   # (hi, mid) bf16 planes of `cur` when the producing convolution emitted them
+        for ii, item in enumerate(cfg):
             n2, ci, hh, ww = cur.shape
             if item[0] == "M":
+                planes = None
                 out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
                 check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
                 saved.append(cur)
@@ -1333,8 +1375,24 @@ class _VggLossFn(torch.autograd.Function):
                 co = weight.shape[0]
                 wk = _ohwi(weight, cpad=ci)
                 out = nhwc_empty(n2, hh, ww, co, dev)
-                check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
-                                        3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
+                wowner = (weakref.ref(weight), weight._version)
+                if split and _sb16_eligible(ci, co):
+                    # split-bf16 path: input planes come from the previous convolution's epilogue when there was one
+                    if planes is None:
+                        planes = _sb16_planes(cur.data_ptr(), ci, ci, n2 * hh * ww, dev)
+                    wh, wm = _sb16_weights(wk, wowner, transpose=False)
+                    nxt = cfg[ii + 1] if ii + 1 < len(cfg) else None
+                    emit = nxt is not None and nxt[0] == "C" and _sb16_eligible(co, params[pi].shape[0])
+                    oh = torch.empty((n2 * hh * ww, co), dtype=torch.bfloat16, device=dev) if emit else None
+                    om = torch.empty_like(oh) if emit else None
+                    check(L.so_sb16_conv3x3(planes[0].data_ptr(), planes[1].data_ptr(), wh.data_ptr(), wm.data_ptr(), bias.data_ptr(),
+                                            None, out.data_ptr(), co, oh.data_ptr() if emit else None, om.data_ptr() if emit else None,
+                                            n2, hh, ww, ci, co, 1, _stream()), "sb16_conv3x3")
+                    planes = (oh, om) if emit else None
+                else:
+                    check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
+                                            3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
+                    planes = None
                 tap_w = item[1]
                 ytap = None  # index in `saved` of the precomputed target feature of this tap
                 if tap_w is not None:
@@ -1356,6 +1414,7 @@ class _VggLossFn(torch.autograd.Function):
             cur = out
         ctx.save_for_backward(*saved)
         ctx.meta = (meta, b, c, cp)
+        ctx.split = split
         return loss
 
     @staticmethod
@@ -1389,10 +1448,17 @@ class _VggLossFn(torch.autograd.Function):
                 check(L.so_l1_loss_bwd(out.data_ptr(), co, yp, co, gout.data_ptr(), tap_w / (rows * co),
                                        g.data_ptr(), co, rows, co, acc, 1, _stream()), "l1_bwd")
             dx = nhwc_empty(b, hh, ww, ci, dev)
-            wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
             gate = saved[relu_in].data_ptr() if relu_in is not None else None  # x half = first b images of the 2b batch
-            check(L.so_conv2d_dgrad_t_gated(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, gate, b, hh, ww, ci, co, 3, 3, 1, 1,
-                                            ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_t")
+            if ctx.split and _sb16_eligible(co, ci):
+                # input gradient = the same split-bf16 convolution on flipped + transposed weight planes ([ci][9][co])
+                gh, gm = _sb16_planes(g.data_ptr(), co, co, rows, dev)
+                wh, wm = _sb16_weights(wk, wkey, transpose=True)
+                check(L.so_sb16_conv3x3(gh.data_ptr(), gm.data_ptr(), wh.data_ptr(), wm.data_ptr(), None, gate, dx.data_ptr(), ci,
+                                        None, None, b, hh, ww, co, ci, 0, _stream()), "sb16_dgrad")
+            else:
+                wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
+                check(L.so_conv2d_dgrad_t_gated(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, gate, b, hh, ww, ci, co, 3, 3, 1, 1,
+                                                ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_t")
             g = dx
         dxr = g if cp == c else g[:, :c]
         return (dxr, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

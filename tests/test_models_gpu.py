@@ -605,3 +605,53 @@ def test_self_attention_lds_resident_core(cuda, c, hw):
         assert_close(g, g0[name], atol=1e-4 + 1e-4 * float(ref.abs().max()), what=f"fused vs composed: d{name}")
     assert_close(y1, y0, atol=1e-5, what="fused vs composed: out")
     assert_close(dx1, dx0, atol=5e-5, what="fused vs composed: dx")
+
+
+def test_vgg_split_bf16_path_stays_within_the_fp32_parity_tolerances(cuda):
+    """Opt-in split-bf16 VGG chain (csrc/sb16.hip: fp32 = hi + mid bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate):
+    perceptual loss and its input gradient against the oracle at the SAME tolerances as the fp32 path, and the full bs = 2
+    attn+gelu training step against the reference golden (losses 2e-5, gradient checksums)."""
+    from shineon_virtual_tryon_amd import ops
+    from shineon_virtual_tryon_amd.networks.loss import VGGLoss
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+
+    default = ops.VGG_SPLIT_BF16
+    ops.VGG_SPLIT_BF16 = True
+    try:
+        torch.manual_seed(3)
+        crit = VGGLoss().to(cuda)
+        g = torch.Generator().manual_seed(21)
+        x = (torch.rand(2, 3, 64, 48, generator=g) * 2 - 1)
+        y = (torch.rand(2, 3, 64, 48, generator=g) * 2 - 1)
+        xs = x.clone().to(cuda).requires_grad_(True)
+        ls = crit(xs, y.to(cuda))
+        ls.backward()
+        ops.VGG_SPLIT_BF16 = False
+        xf = x.clone().to(cuda).requires_grad_(True)
+        lf = crit(xf, y.to(cuda))
+        lf.backward()
+        ops.VGG_SPLIT_BF16 = True
+        sd = {"v." + k: v.detach().cpu() for k, v in crit.state_dict().items()}
+        xc = x.clone().requires_grad_(True)
+        lr = oracle.vgg_loss(sd, xc, y, prefix="v.vgg")
+        lr.backward()
+        assert abs(float(ls) - float(lr)) <= 2e-5 * abs(float(lr)), (float(ls), float(lr))
+        gmax = float(xc.grad.abs().max())
+        assert_close(xs.grad, xc.grad, atol=1e-7 + 2e-3 * gmax, what="split-bf16 vgg dx vs oracle")
+        print(f"[vgg split-bf16] loss rel err {abs(float(ls) - float(lr)) / abs(float(lr)):.2e} (fp32 path "
+              f"{abs(float(lf) - float(lr)) / abs(float(lr)):.2e}); dx max err / max {float((xs.grad.cpu() - xc.grad).abs().max()) / gmax:.2e} "
+              f"(fp32 path {float((xf.grad.cpu() - xc.grad).abs().max()) / gmax:.2e})")
+        # whole try-on training step against the reference golden
+        variant = "attn_gelu"
+        gold = load_golden(f"unet_mask_{variant}.npz")
+        model = _load(UnetMaskModel(make_namespace(**UNET_VARIANTS[variant])), golden_state(gold), cuda).train()
+        res = model.training_step(_to(synthetic_cpu_batch(2), cuda), 0)
+        res.minimize.backward()
+        for k in ("loss/G", "loss/G/l1", "loss/G/vgg", "loss/G/tryon_mask_l1"):
+            ref = float(gold["log:" + k])
+            assert abs(float(res.logs[k]) - ref) <= 2e-5 + 2e-5 * abs(ref), (k, float(res.logs[k]), ref)
+        params = dict(model.named_parameters())
+        for k in [k for k in gold.files if k.startswith("gcs:")]:
+            assert_checksums(params[k[4:]].grad, gold[k], rel=1e-2, what=f"split-bf16 {k}", floor=4e-5)
+    finally:
+        ops.VGG_SPLIT_BF16 = default
