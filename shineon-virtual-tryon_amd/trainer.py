@@ -31,9 +31,11 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0, max(world, 1)
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    # SHINEON_DIST_BACKEND=gloo: functional runs of the multi-rank code path where RCCL cannot be used (e.g. two ranks
+    # sharing ONE GPU in tests/test_multi_gpu.py); SHINEON_LOCAL_DEVICE pins the device index independently of LOCAL_RANK
+    backend = backend or os.environ.get("SHINEON_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(int(os.environ.get("SHINEON_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     dist.init_process_group(backend=backend)
     return dist.get_rank(), dist.get_world_size()
 
