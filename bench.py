@@ -153,6 +153,7 @@ def hbm_table(dev, batch_size):
     cases = {}
     npar = 41_704_826  # trainable parameters of the two models (19.06 M + 22.65 M)
     p, g, m, v = (f(npar) for _ in range(4))
+    v.abs_()  # second moments are non-negative
     cases["adam_step (41.7 M params, 28 B/param)"] = (
         lambda: L.so_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), npar, 1e-4, 0.9, 0.999, 1e-8, 3, 1.0, st),
         npar * 28)

@@ -33,8 +33,8 @@ __global__ void split_k(const float* __restrict__ x, u16* __restrict__ hi, u16* 
 }
 
 // NP = number of products: 6 or 3 (or 1 = plain bf16)
-template <int BM, int BN, int NP>
-__global__ __launch_bounds__(256, 1) void sb16_gemm_k(const u16* Ah, const u16* Am, const u16* Al, const u16* Bh, const u16* Bm,
+template <int BM, int BN, int NP, int SB = 0, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void sb16_gemm_k(const u16* Ah, const u16* Am, const u16* Al, const u16* Bh, const u16* Bm,
                                                      const u16* Bl, float* C, int M, int N, int K) {
   constexpr int BK = 32;            // bf16 elements per K tile = 64 bytes per row
   constexpr int PITCH = 40;         // u16 per LDS row (80 bytes): conflict-free ds_read_b128
@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256, 1) void sb16_gemm_k(const u16* Ah, const u16* 
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     const u16* s = smem + cur * STAGE;
-    if (kt + 1 < nkt) lstore(cur ^ 1);
-    if (kt + 2 < nkt) gload(kt + 2);
+    if (!SB) {
+      if (kt + 1 < nkt) lstore(cur ^ 1);
+      if (kt + 2 < nkt) gload(kt + 2);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[NPL][TM], fb[NPL][TN];
@@ -117,7 +119,13 @@ __global__ __launch_bounds__(256, 1) void sb16_gemm_k(const u16* Ah, const u16* 
         }
     }
     __syncthreads();
-    cur ^= 1;
+    if (SB) {  // single LDS stage: tile kt + 1 waits in registers during the MFMAs, then replaces the stage
+      if (kt + 1 < nkt) lstore(0);
+      if (kt + 2 < nkt) gload(kt + 2);
+      __syncthreads();
+    } else {
+      cur ^= 1;
+    }
   }
   for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) {
     const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -125,12 +133,12 @@ __global__ __launch_bounds__(256, 1) void sb16_gemm_k(const u16* Ah, const u16* 
   }
 }
 
-template <int BM, int BN, int NP>
+template <int BM, int BN, int NP, int SB = 0, int OCC = 1>
 void run(const char* name, u16** A, u16** B, float* C, int M, int N, int K, const std::vector<float>& hA, const std::vector<float>& hB) {
   if (M % BM || N % BN) return;
   constexpr int NPL = NP == 1 ? 1 : (NP == 3 ? 2 : 3);
-  const size_t lds = (size_t)2 * NPL * (BM + BN) * 40 * 2;
-  auto k = sb16_gemm_k<BM, BN, NP>;
+  const size_t lds = (size_t)(SB ? 1 : 2) * NPL * (BM + BN) * 40 * 2;
+  auto k = sb16_gemm_k<BM, BN, NP, SB, OCC>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { printf("%s attr fail (lds %zu)\n", name, lds); return; }
   dim3 grid((M / BM) * (N / BN));
   const int w = (int)(80e-3 / (2.0 * M * N * K / 300e12)) + 2;
@@ -159,7 +167,7 @@ void run(const char* name, u16** A, u16** B, float* C, int M, int N, int K, cons
 }
 
 int main() {
-  const int shapes[][3] = {{24576, 256, 2304}, {6144, 512, 4608}, {98304, 128, 1152}, {393216, 64, 576}, {4096, 4096, 4096}};
+  const int shapes[][3] = {{24576, 256, 2304}, {6144, 512, 4608}, {98304, 128, 1152}, {4096, 4096, 4096}};
   for (auto& s : shapes) {
     const int M = s[0], N = s[1], K = s[2];
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
@@ -175,12 +183,17 @@ int main() {
     hipLaunchKernelGGL(split_k, dim3((hB.size() + 255) / 256), dim3(256), 0, 0, dB, B[0], B[1], B[2], hB.size());
     hipDeviceSynchronize();
     printf("M=%d N=%d K=%d (%.1f GF)\n", M, N, K, 2.0 * M * N * K / 1e9);
-    run<128, 128, 6>("x6 128x128", A, B, C, M, N, K, hA, hB);
-    run<128, 128, 3>("x3 128x128", A, B, C, M, N, K, hA, hB);
-    run<128, 128, 1>("x1 128x128 (plain bf16)", A, B, C, M, N, K, hA, hB);
-    run<128, 64, 6>("x6 128x64", A, B, C, M, N, K, hA, hB);
-    run<64, 64, 6>("x6 64x64", A, B, C, M, N, K, hA, hB);
-    run<64, 64, 3>("x3 64x64", A, B, C, M, N, K, hA, hB);
+    run<128, 128, 3>("x3 128x128 dbuf occ1", A, B, C, M, N, K, hA, hB);
+    run<128, 128, 3, 1, 2>("x3 128x128 sbuf occ2", A, B, C, M, N, K, hA, hB);
+    run<128, 128, 3, 1, 3>("x3 128x128 sbuf occ3", A, B, C, M, N, K, hA, hB);
+    run<128, 256, 3>("x3 128x256 dbuf occ1", A, B, C, M, N, K, hA, hB);
+    run<256, 128, 3>("x3 256x128 dbuf occ1", A, B, C, M, N, K, hA, hB);
+    run<128, 256, 3, 1, 1>("x3 128x256 sbuf occ1", A, B, C, M, N, K, hA, hB);
+    run<128, 256, 3, 1, 2>("x3 128x256 sbuf occ2", A, B, C, M, N, K, hA, hB);
+    run<64, 128, 3, 1, 3>("x3 64x128 sbuf occ3", A, B, C, M, N, K, hA, hB);
+    run<64, 128, 3, 0, 2>("x3 64x128 dbuf occ2", A, B, C, M, N, K, hA, hB);
+    run<128, 128, 6, 1, 2>("x6 128x128 sbuf occ2", A, B, C, M, N, K, hA, hB);
+    run<128, 256, 6, 1, 1>("x6 128x256 sbuf occ1", A, B, C, M, N, K, hA, hB);
     hipFree(dA); hipFree(dB); hipFree(C);
     for (int p = 0; p < 3; ++p) { hipFree(A[p]); hipFree(B[p]); }
   }
