@@ -655,3 +655,47 @@ def test_vgg_split_bf16_path_stays_within_the_fp32_parity_tolerances(cuda):
             assert_checksums(params[k[4:]].grad, gold[k], rel=1e-2, what=f"split-bf16 {k}", floor=4e-5)
     finally:
         ops.VGG_SPLIT_BF16 = default
+
+
+def test_trainer_fit_chained_equals_sequential_loop(cuda):
+    """Trainer.fit_chained - the product API behind bench.py's step (trainer.ChainedTrainStep: three hipGraphs on two
+    streams, deferred try-on Adam) - trains both stages exactly like the plain sequential eager loop over the same batches:
+    bit-identical parameters and BatchNorm statistics after four chained steps on changing batches."""
+    import copy
+
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.trainer import Trainer
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+    from shineon_virtual_tryon_amd.warp_model import WarpModel
+
+    torch.manual_seed(17)
+    warp_a = WarpModel(make_namespace(person_inputs=["agnostic", "cocopose"], lr=1e-3)).to(cuda).train()
+    unet_a = UnetMaskModel(make_namespace(self_attn=True, activation="gelu", lr=1e-3)).to(cuda).train()
+    for m in unet_a.modules():
+        if hasattr(m, "gamma"):
+            m.gamma.data.fill_(0.3)
+    warp_b, unet_b = copy.deepcopy(warp_a), copy.deepcopy(unet_a)
+    for m in (warp_a, unet_a, warp_b, unet_b):
+        m.global_step = 1
+    batches = [synthetic_batch(2, cuda, smooth=True, start=2 * i) for i in range(4)]
+
+    optw = warp_a.configure_optimizers()[0][0]
+    optu = unet_a.configure_optimizers()[0][0]
+    for batch in batches:
+        optw.zero_grad()
+        warp_a.training_step(batch, 0).minimize.backward()
+        optw.step()
+        b2 = dict(batch)
+        b2["cloth"] = warp_a.warped_cloth.detach()
+        optu.zero_grad()
+        unet_a.training_step(b2, 0).minimize.backward()
+        optu.step()
+    torch.cuda.synchronize()
+
+    engine = Trainer(graph=True, overlap=True).fit_chained(warp_b, unet_b, batches, steps=4)
+    assert engine.schedule == "pipeline"
+    for (ka, va), (kb, vb) in zip(warp_a.state_dict().items(), warp_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), f"warp {ka}"
+    for (ka, va), (kb, vb) in zip(unet_a.state_dict().items(), unet_b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), f"unet {ka}"
+    assert engine.optw._steps == 4 and engine.optu._steps == 4
