@@ -41,12 +41,15 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
-GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8}
+GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None}  # c5: taken from the MFMA launches' own 2MNK sum
 WORKLOADS = {
     "c4": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then UnetMaskModel "
           "(self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, 256x192",
     "c2": "BASELINE config 2: WarpModel (GMM feature-extract + correlation + TPS grid_sample) fwd+bwd+Adam, 256x192",
     "c3": "BASELINE config 3: UnetMaskModel (self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam, 256x192",
+    "c5": "BASELINE config 5: UnetMaskModel with n_frames_total=5, flow_warp (ngf=167, 50 in / 25 out channels, 154 M parameters, "
+          "Resample2d chain, flow-mask penalty), bs=2 sequences of 5 frames per GPU, fwd+bwd+Adam, 256x192; flow fields synthetic "
+          "(FlowNet2 stays upstream)",
 }
 
 
@@ -94,7 +97,11 @@ def cpu_baseline(config, batch_size, iters=5, warmup=2, budget_s=45.0):
 
     torch.set_num_threads(usable_cores())
     log(f"cpu_baseline: {torch.get_num_threads()} threads on {cpu_model()}")
-    batch = synthetic_batch(batch_size, "cpu")
+    nfr = 5 if config == "c5" else 1
+    batch = synthetic_batch(batch_size, "cpu", n_frames=nfr)
+    if nfr > 1:
+        batch = {k: (v.reshape(v.shape[0], -1, *v.shape[3:]) if isinstance(v, torch.Tensor) and v.dim() == 5 else v)
+                 for k, v in batch.items()}
     steps = []
     if config in ("c2", "c4"):
         warp_sd = procedural_state_dict(shapes_of(WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).state_dict()))
@@ -102,12 +109,13 @@ def cpu_baseline(config, batch_size, iters=5, warmup=2, budget_s=45.0):
         optw = torch.optim.Adam([v for v in wp.values() if v.requires_grad], 1e-4)
         consts = oracle.tps_constants(256, 192, 5)
         whp = dict(person_inputs=["agnostic", "cocopose"], cloth_inputs=["cloth"])
-    if config in ("c3", "c4"):
-        unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).state_dict()))
+    if config in ("c3", "c4", "c5"):
+        extra = dict(n_frames_total=5, flow_warp=True) if config == "c5" else {}
+        unet_sd = procedural_state_dict(shapes_of(UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"], **extra)).state_dict()))
         up = {k: v.clone().requires_grad_(k.startswith("unet.")) for k, v in unet_sd.items()}
         optu = torch.optim.Adam([v for v in up.values() if v.requires_grad], 1e-4)
-        uhp = dict(n_frames_total=1, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], self_attn=True,
-                   num_attn=2, activation="gelu", flow_warp=False)
+        uhp = dict(n_frames_total=nfr, person_inputs=["agnostic", "densepose"], cloth_inputs=["cloth"], self_attn=True,
+                   num_attn=2, activation="gelu", flow_warp=nfr > 1)
 
     def step():
         b2 = batch
@@ -118,7 +126,7 @@ def cpu_baseline(config, batch_size, iters=5, warmup=2, budget_s=45.0):
             optw.step()
             b2 = dict(batch)
             b2["cloth"] = out["warped_cloth"].detach()
-        if config in ("c3", "c4"):
+        if config in ("c3", "c4", "c5"):
             optu.zero_grad()
             oracle.unet_mask_losses(up, b2, uhp)["loss/G"].backward()
             optu.step()
@@ -135,8 +143,8 @@ def cpu_baseline(config, batch_size, iters=5, warmup=2, budget_s=45.0):
     steps.sort()
     med = steps[len(steps) // 2]
     what = {"c4": "chained steps (WarpModel + UnetMaskModel fwd+bwd+Adam", "c2": "WarpModel steps (fwd+bwd+Adam",
-            "c3": "UnetMaskModel steps (fwd+bwd+Adam"}[config]
-    return {"value": batch_size / med, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "c3": "UnetMaskModel steps (fwd+bwd+Adam", "c5": "5-frame flow_warp UnetMaskModel steps (fwd+bwd+Adam"}[config]
+    return {"value": batch_size * nfr / med, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
             "sample": f"{warmup} warm-up + {len(steps)} timed {what}, bs={batch_size}, 256x192) with PyTorch CPU fp32, "
                       f"median {med * 1e3:.0f} ms/step (min {steps[0] * 1e3:.0f}, max {steps[-1] * 1e3:.0f})"}
 
@@ -197,8 +205,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (BASELINE: 4)")
-    ap.add_argument("--config", choices=("c4", "c2", "c3"), default="c4",
-                    help="c4: chained warp->try-on step (headline); c2: WarpModel alone; c3: UnetMaskModel alone")
+    ap.add_argument("--config", choices=("c4", "c2", "c3", "c5"), default="c4",
+                    help="c4: chained warp->try-on step (headline); c2: WarpModel alone; c3: UnetMaskModel alone; "
+                         "c5: 5-frame flow_warp UnetMaskModel, bs=2 sequences (frames/s counts bs x 5 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--cpu-iters", type=int, default=5)
@@ -228,14 +237,18 @@ def main():
 
         so_ops.VGG_SPLIT_BF16 = True
     torch.manual_seed(420)
-    batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch)
     cfg = args.config
+    if cfg == "c5" and args.batch == 4:
+        args.batch = 2   # BASELINE config 5: bs = 2 per GPU
+    nfr = 5 if cfg == "c5" else 1
+    batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch, n_frames=nfr)
     warp = unet = None
     if cfg in ("c2", "c4"):
         warp = WarpModel(hparams(person_inputs=["agnostic", "cocopose"])).to(dev).train()
         warp.global_step = 1
-    if cfg in ("c3", "c4"):
-        unet = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).to(dev).train()
+    if cfg in ("c3", "c4", "c5"):
+        extra = dict(n_frames_total=5, flow_warp=True) if cfg == "c5" else {}
+        unet = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"], **extra)).to(dev).train()
         unet.global_step = 1
 
     if cfg == "c4":
@@ -319,10 +332,12 @@ def main():
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
         mfma_ms = sum(ms) / prof_steps
         step_ms = 1e3 * elapsed / args.steps
-        step_tflops = GF_PER_FRAME[cfg] * args.batch / step_ms  # GF / ms = TFLOP/s (per GPU: weak scaling)
+        gf_step = GF_PER_FRAME[cfg] * args.batch if GF_PER_FRAME[cfg] else sum(fl) / prof_steps / 1e9
+        step_tflops = gf_step / step_ms  # GF / ms = TFLOP/s (per GPU: weak scaling)
         out = {
-            "metric": "try-on frames/sec (fwd+bwd) at 256x192 bs=4",
-            "value": world * args.batch * args.steps / elapsed,
+            "metric": "try-on frames/sec (fwd+bwd) at 256x192 bs=4" if cfg != "c5" else
+                      "try-on frames/sec (fwd+bwd) at 256x192, n_frames=5 video batch bs=2",
+            "value": world * args.batch * nfr * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -335,7 +350,7 @@ def main():
                       "fp32; frozen VGG19 chain as 3x bf16-split MFMA (hi*hi + hi*mid + mid*hi, fp32 accumulate) - non-headline"),
             "data": "synthetic",
             "config": {"workload": WORKLOADS[cfg], "config": cfg, "launch": launch, "batch_per_gpu": args.batch,
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "global_batch": world * args.batch, "frames_per_sample": nfr, "parallelism": f"dp{world}",
                        "step_api": "shineon_virtual_tryon_amd.trainer." + ("ChainedTrainStep" if cfg == "c4" else "TrainStep")},
             "roofline": {
                 "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
@@ -347,7 +362,7 @@ def main():
                            f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the "
                            "graph-replayed timed region"),
                 "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
-                "step": {"algorithmic_gflop_per_step": GF_PER_FRAME[cfg] * args.batch, "achieved": step_tflops,
+                "step": {"algorithmic_gflop_per_step": gf_step, "achieved": step_tflops,
                          "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                          "note": "whole step incl. every non-GEMM kernel, Adam and launch gaps: algorithmic FLOPs (SURVEY 8d) / "
                                  "measured step time / fp32-MFMA peak"},
