@@ -32,11 +32,16 @@ def init_distributed(backend=None):
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0, max(world, 1)
     # SHINEON_DIST_BACKEND=gloo: functional runs of the multi-rank code path where RCCL cannot be used (e.g. two ranks
-    # sharing ONE GPU in tests/test_multi_gpu.py); SHINEON_LOCAL_DEVICE pins the device index independently of LOCAL_RANK
+    # sharing ONE GPU in tests/test_00_multi_rank_gpu.py); SHINEON_LOCAL_DEVICE pins the device index independently of LOCAL_RANK
     backend = backend or os.environ.get("SHINEON_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("SHINEON_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    dist.init_process_group(backend=backend)
+    kw = {}
+    if os.environ.get("SHINEON_DIST_TIMEOUT_S"):  # tests: fail a broken rendezvous in minutes, not in the 30-minute default
+        import datetime
+
+        kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SHINEON_DIST_TIMEOUT_S"]))
+    dist.init_process_group(backend=backend, **kw)
     return dist.get_rank(), dist.get_world_size()
 
 

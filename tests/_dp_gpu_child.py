@@ -1,4 +1,4 @@
-"""Child process of tests/test_multi_gpu.py: one rank of a 2-rank data-parallel run (started as a fresh python process,
+"""Child process of tests/test_00_multi_rank_gpu.py: one rank of a 2-rank data-parallel run (started as a fresh python process,
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment; backend nccl = RCCL on two GPUs, or gloo with both ranks on
 one GPU).
 

@@ -243,7 +243,7 @@ print("DP_OK", rank)
 def test_data_parallel_reducer_world2_gloo(tmp_path):
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
