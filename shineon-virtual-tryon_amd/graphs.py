@@ -82,6 +82,8 @@ class GraphedChainedStep:
         clone = lambda: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}
         self.batch_warp, self.batch_tryon = clone(), clone()
         sb = self.batch_warp
+        self.keys_warp = warp.batch_keys() if hasattr(warp, "batch_keys") else None
+        self.keys_tryon = (unet.batch_keys() - {"cloth"}) if hasattr(unet, "batch_keys") else None  # cloth comes from the warp stage
         self.side = torch.cuda.Stream()
         self.fwd_done, self.cloth_taken = torch.cuda.Event(), torch.cuda.Event()
         optw.zero_grad()
@@ -130,10 +132,12 @@ class GraphedChainedStep:
         self._first = True
 
     @staticmethod
-    def _load(dst, batch):
+    def _load(dst, batch, keys=None):
+        """Copy a new batch into a stage's static buffers; `keys`: only the entries that stage reads."""
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
-                dst[k].copy_(v, non_blocking=True)
+                if (keys is None or k in keys) and k in dst:
+                    dst[k].copy_(v, non_blocking=True)
             else:
                 dst[k] = v
 
@@ -147,7 +151,7 @@ class GraphedChainedStep:
             self.side.wait_event(self.cloth_taken)
         with torch.cuda.stream(self.side):
             if batch is not None:
-                self._load(self.batch_warp, batch)
+                self._load(self.batch_warp, batch, self.keys_warp)
             self.g_wf.replay()
             self.fwd_done.record(self.side)
 
@@ -155,7 +159,7 @@ class GraphedChainedStep:
         """main stream: (load the new batch,) take the warped cloth, then try-on forward + backward."""
         main = torch.cuda.current_stream()
         if batch is not None:
-            self._load(self.batch_tryon, batch)
+            self._load(self.batch_tryon, batch, self.keys_tryon)
         main.wait_event(self.fwd_done)
         self.cloth_tryon.copy_(self.warped, non_blocking=True)
         self.cloth_taken.record(main)

@@ -17,6 +17,7 @@ import logging
 import os
 import os.path as osp
 import signal
+import time
 
 import torch
 import torch.distributed as dist
@@ -377,12 +378,14 @@ class DeviceBatches:
     of a per-sample CPU pipeline.  Rank r of w takes indices r::w of the (optionally shuffled) epoch order, like
     DistributedSampler (base_model.py:113-121)."""
 
-    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, limit=None):
+    def __init__(self, dataset, batch_size, device, shuffle=True, seed=0, limit=None, keys=None):
+        """keys: keep only these tensor entries resident (the ones the model reads); None keeps all."""
         from torch.utils.data.dataloader import default_collate
 
         n = len(dataset) if limit is None else min(len(dataset), limit)
         full = default_collate([dataset[i] for i in range(n)])
-        self.tensors = {k: v.to(device) for k, v in full.items() if isinstance(v, torch.Tensor)}
+        self.tensors = {k: v.to(device) for k, v in full.items()
+                        if isinstance(v, torch.Tensor) and (keys is None or k in keys)}
         self.other = {k: v for k, v in full.items() if not isinstance(v, torch.Tensor)}
         self.n, self.batch_size, self.device, self.shuffle, self.seed = n, batch_size, device, shuffle, seed
         self.rank = dist.get_rank() if _world() > 1 else 0
@@ -444,6 +447,7 @@ class Trainer:
         self.current_epoch = 0
         self.model = self.optimizer = self.scheduler = None
         self._interrupted = False
+        self.epoch_seconds = []
 
     # ---- checkpoints (Lightning-style dict so reference checkpoints' state_dict drops in) --------------
     def save_checkpoint(self, path, epoch_finished=False):
@@ -501,8 +505,9 @@ class Trainer:
             return model.train_dataloader(), model.val_dataloader()
         hp = model.hparams
         shuffle = not getattr(hp, "no_shuffle", False)
-        return (DeviceBatches(model.train_dataset, hp.batch_size, self.device, shuffle=shuffle),
-                DeviceBatches(model.val_dataset, hp.batch_size, self.device, shuffle=False))
+        keys = model.batch_keys() if hasattr(model, "batch_keys") else None
+        return (DeviceBatches(model.train_dataset, hp.batch_size, self.device, shuffle=shuffle, keys=keys),
+                DeviceBatches(model.val_dataset, hp.batch_size, self.device, shuffle=False, keys=keys))
 
     def _on_sigint(self, *_):
         # only set a flag: the checkpoint is written at the next step boundary, after the streams have drained
@@ -533,6 +538,7 @@ class Trainer:
                     if hasattr(obj, "set_epoch"):
                         obj.set_epoch(epoch)
                 model.train()
+                t_epoch = time.perf_counter()
                 for i, batch in enumerate(train_loader):
                     if i >= n_train or (self.fast_dev_run and i >= 1):
                         break
@@ -557,6 +563,8 @@ class Trainer:
                         model.train()
                 if step is not None:
                     step.flush()
+                torch.cuda.synchronize()   # once per epoch: wall time of the epoch for throughput reports
+                self.epoch_seconds.append(time.perf_counter() - t_epoch)
                 self.scheduler.step()
         except KeyboardInterrupt:
             raise SystemExit(130)

@@ -66,6 +66,11 @@ class UnetMaskModel(BaseModel):
         self.criterionVGG = VGGLoss(weights_file=getattr(hparams, "vgg_weights", None))
         init_weights(self.unet, init_type="normal")
 
+    def batch_keys(self):
+        """Tensor entries of the batch dict this model reads (training / validation / test)."""
+        keys = set(self.hparams.person_inputs) | set(self.hparams.cloth_inputs) | {"image", "prev_image", "cloth_mask"}
+        return keys | ({"flow"} if self.hparams.flow_warp else set())
+
     def require_pretrained_vgg(self):
         """Called by Trainer.fit before training starts: the reference always trains against ImageNet VGG19 features
         (models/networks/vgg.py:9); refuse to optimise against random ones unless explicitly allowed.  A checkpoint

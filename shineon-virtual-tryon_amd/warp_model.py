@@ -40,6 +40,10 @@ class WarpModel(BaseModel):
         self.regression = FeatureRegression(input_nc=192, output_dim=2 * hparams.grid_size ** 2)
         self.gridGen = TpsGridGen(hparams.fine_height, hparams.fine_width, grid_size=hparams.grid_size)
 
+    def batch_keys(self):
+        """Tensor entries of the batch dict this model reads (training / validation / test)."""
+        return set(self.hparams.person_inputs) | set(self.hparams.cloth_inputs) | {"cloth", "im_cloth", "cloth_mask", "grid_vis"}
+
     def plant_shared_buffers(self):
         """Re-home the 14 num_batches_tracked counters as views of ONE int64 tensor (layers.share_bn_counters) and
         return it; idempotent until the buffers are moved by .to()."""
