@@ -84,7 +84,7 @@ class GraphedChainedStep:
         sb = self.batch_warp
         self.keys_warp = warp.batch_keys() if hasattr(warp, "batch_keys") else None
         self.keys_tryon = (unet.batch_keys() - {"cloth"}) if hasattr(unet, "batch_keys") else None  # cloth comes from the warp stage
-        self.side = torch.cuda.Stream()
+        self.side = _side_stream()
         self.fwd_done, self.cloth_taken = torch.cuda.Event(), torch.cuda.Event()
         optw.zero_grad()
         optu.zero_grad()
@@ -175,6 +175,30 @@ class GraphedChainedStep:
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+def _side_stream():
+    """The stream of the warp stage.  SHINEON_SIDE_CUS=<n> (experiment): confine it to the first n compute units with
+    hipExtStreamCreateWithCUMask, so that the warp stage's many short kernels would fill in beside the try-on stage's large
+    GEMMs without taking CUs from all of them.  Measured on MI355X (bench.py c4): 8.98 ms/step unmasked, 19.1 / 14.5 / 11.9 /
+    11.2 ms with 32 / 64 / 128 / 192 CUs - the warp forward sits on the next step's critical path, so slowing it stalls the
+    pipeline; left in as a switch, off by default."""
+    import ctypes
+    import os
+
+    n = int(os.environ.get("SHINEON_SIDE_CUS", "0") or 0)
+    if n <= 0:
+        return torch.cuda.Stream()
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (n + 31) // 32
+    mask = (ctypes.c_uint32 * 8)(*([0] * 8))
+    for i in range(n):
+        mask[i // 32] |= 1 << (i % 32)
+    stream = ctypes.c_void_p()
+    err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(max(words, 8)), mask)
+    if err != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {err}")
+    return torch.cuda.ExternalStream(stream.value)
 
 
 def _detached(res):
