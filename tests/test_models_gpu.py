@@ -699,3 +699,45 @@ def test_trainer_fit_chained_equals_sequential_loop(cuda):
     for (ka, va), (kb, vb) in zip(unet_a.state_dict().items(), unet_b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), f"unet {ka}"
     assert engine.optw._steps == 4 and engine.optu._steps == 4
+
+
+def test_train_step_gradient_accumulation_matches_the_full_batch(cuda):
+    """trainer.TrainStep(accumulate=2) on two half batches (the reference's --accumulated_batches, train.py:76-118 ->
+    Lightning accumulate_grad_batches) applies ONE optimizer step whose gradient is the full batch's: InstanceNorm and
+    attention are per-sample and every loss is a batch mean, so the parameters after the step agree with a bs = 4 step."""
+    import copy
+
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.trainer import TrainStep
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+
+    torch.manual_seed(23)
+    a = UnetMaskModel(make_namespace(self_attn=True, activation="gelu", lr=1e-3)).to(cuda).train()
+    for m in a.modules():
+        if hasattr(m, "gamma"):
+            m.gamma.data.fill_(0.3)
+    b = copy.deepcopy(a)
+    a.global_step = b.global_step = 1
+    full = synthetic_batch(4, cuda, smooth=True)
+    half = lambda lo: {k: (v[lo:lo + 2].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in full.items()}  # noqa: E731
+    (opta,), _ = a.configure_optimizers()
+    (optb,), _ = b.configure_optimizers()
+    ea = TrainStep(a, opta, full, graph=False, overlap=False)
+    ea(full)
+    eb = TrainStep(b, optb, half(0), graph=True, overlap=True, accumulate=2)   # accumulation forces the eager path
+    assert eb.graph is False
+    eb(half(0))
+    assert not eb.stepped and optb._steps == 0
+    eb(half(2))
+    eb.flush()
+    assert eb.stepped and optb._steps == 1 and opta._steps == 1
+    torch.cuda.synchronize()
+    # Adam's first step moves every weight by ~lr * sign(g): compare the gradients themselves (kept in the slabs)
+    ga, gb = opta.flat_grads, optb.flat_grads
+    scale = float(ga.abs().max())
+    # per-parameter comparison at the parity tolerance
+    for (name, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        if p.requires_grad and p.numel() > 1:
+            tol = 2e-3 * float(p.grad.abs().max()) + 2e-7
+            assert float((p.grad - q.grad).abs().max()) <= tol, name
+    assert scale > 0
