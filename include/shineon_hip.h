@@ -306,6 +306,10 @@ long long so_silhouette_ws_bytes(int Nb, int H, int W, int factor);
 int so_silhouette(const void* shape_u8, float* silhouette, long long stride_out, void* ws, int Nb, int H, int W, int factor,
                   void* stream);
 
+/* get_input_cloth_mask (tryon_dataset.py:168-175): mask [Nb][1][HW] = (x[:, 0] >= threshold) ? 0 : 1 for planar x [Nb][C][HW].
+ * NB the reference compares the NORMALISED cloth (values in [-1, 1]) with its default threshold 240, so its mask is all ones. */
+int so_threshold_mask(const float* x, int C, float threshold, float* mask, int Nb, int HW, void* stream);
+
 /* get_person_flow (tryon_dataset.py:272-298): .flo payload [Nb][HW][2] (u, v interleaved) -> planar [Nb][2][HW]
  * followed by transforms.Normalize((0.5, 0.5), (0.5, 0.5)). */
 int so_flow_decode(const float* payload, float* flow, int Nb, int HW, void* stream);

@@ -57,6 +57,13 @@ def head_and_cloth(image, parse):
     return image * mh - (1 - mh), image * mc + (1 - mc)
 
 
+def cloth_mask(cloth, threshold=240):
+    """get_input_cloth_mask (tryon_dataset.py:168-175): where(cloth >= threshold, 0, 1)[0:1].  (The reference's default
+    threshold 240 is compared with the NORMALISED cloth, so its mask is all ones.)"""
+    c = np.asarray(cloth, np.float32)
+    return np.where(c >= np.float32(threshold), np.float32(0), np.float32(1))[0:1].astype(np.float32)
+
+
 def _pil_coeffs(in_size, out_size):
     """Pillow precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (support 1.0)."""
     scale = in_size / out_size

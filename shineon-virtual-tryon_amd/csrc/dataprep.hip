@@ -167,6 +167,16 @@ __global__ __launch_bounds__(256) void flow_decode_k(const float* __restrict__ p
     flow[(n * 2 + c) * HW + pix] = __fdiv_rn(__fsub_rn(payload[i * 2 + c], 0.5f), 0.5f);
 }
 
+// get_input_cloth_mask (tryon_dataset.py:168-175): mask = (cloth[channel 0] >= threshold) ? 0 : 1, one channel.
+__global__ __launch_bounds__(256) void threshold_mask_k(const float* __restrict__ x, int C, float threshold,
+                                                        float* __restrict__ mask, int HW, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over N*HW
+  if (i >= total) return;
+  const long long n = i / HW;
+  const int pix = (int)(i - n * HW);
+  mask[i] = x[n * C * HW + pix] >= threshold ? 0.0f : 1.0f;
+}
+
 inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -236,6 +246,14 @@ int so_silhouette(const void* shape_u8, float* silhouette, long long stride_out,
   t = (long long)Nb * H * W;
   hipLaunchKernelGGL(pil_bilinear_pass_k, dim3(blocks_for(t)), dim3(256), 0, st, (const unsigned char*)c,
                      (unsigned char*)nullptr, silhouette, stride_out, W, h2, W, H, 0, t);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_threshold_mask(const float* x, int C, float threshold, float* mask, int Nb, int HW, void* stream) {
+  const long long total = (long long)Nb * HW;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(threshold_mask_k, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, x, C, threshold, mask, HW,
+                     total);
   return SO_LAUNCH_CHECK();
 }
 

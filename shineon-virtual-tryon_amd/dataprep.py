@@ -111,6 +111,53 @@ def flow_from_payload(payload):
     return out
 
 
+def cloth_mask(cloth, threshold=240.0):
+    """get_input_cloth_mask (tryon_dataset.py:168-175): (cloth[:, 0] >= threshold) ? 0 : 1 -> (N, 1, H, W).  The reference
+    applies its default threshold 240 (--cloth_mask_threshold, a 0-255 value) to the NORMALISED cloth in [-1, 1], so with the
+    default the mask is all ones; that behaviour is reproduced as is."""
+    _require_cuda(cloth)
+    c = cloth.contiguous()
+    n, ch, h, w = c.shape
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=c.device)
+    check(lib().so_threshold_mask(c.data_ptr(), ch, float(threshold), out.data_ptr(), n, h * w, _stream()), "threshold_mask")
+    return out
+
+
+def build_batch(raw, radius=5, cloth_mask_threshold=240.0, draw_pose_into_map=False):
+    """The tensor part of TryonDataset.__getitem__ (tryon_dataset.py:481-537 = get_cloth_representation :209-250 +
+    get_input_cloth / get_input_cloth_mask :156-184 + get_person_flow :272-298) for a whole batch, on the GPU.
+
+    raw: device tensors as stored on disk -
+      image_u8 (N, H, W, 3), cloth_u8 (N, H, W, 3), parse_u8 (N, H, W) LIP labels, keypoints (N, 18, 3) fp64 (NaN = no person);
+      optional prev_image_u8, densepose_u8 (N, H, W, 3), flow_payload (N, H, W, 2) fp32, grid_u8 (N, H, W, 3).
+    Returns the batch dict entries the models read (image, prev_image, cloth, cloth_mask, im_cloth, silhouette, im_head,
+    agnostic, cocopose, im_cocopose, densepose, [flow], [grid_vis]); missing optional inputs give the zeros the reference
+    substitutes for a missing file (:262-266, :293-294, :311-312)."""
+    image = images_to_normed(raw["image_u8"])
+    n, _, h, w = image.shape
+    dev = image.device
+    out = {"image": image}
+    out["prev_image"] = images_to_normed(raw["prev_image_u8"]) if raw.get("prev_image_u8") is not None else \
+        _zeros((n, 3, h, w), dev)
+    out["cloth"] = images_to_normed(raw["cloth_u8"])
+    out["cloth_mask"] = cloth_mask(out["cloth"], cloth_mask_threshold)
+    rep = person_representation(raw["parse_u8"], image)
+    out.update(silhouette=rep["silhouette"], im_head=rep["im_head"], im_cloth=rep["im_cloth"], agnostic=rep["agnostic"])
+    out["cocopose"], out["im_cocopose"] = pose_maps(raw["keypoints"], h, w, radius, draw_pose_into_map)
+    out["densepose"] = images_to_normed(raw["densepose_u8"]) if raw.get("densepose_u8") is not None else _zeros((n, 3, h, w), dev)
+    if raw.get("flow_payload") is not None:
+        out["flow"] = flow_from_payload(raw["flow_payload"])
+    if raw.get("grid_u8") is not None:
+        out["grid_vis"] = images_to_normed(raw["grid_u8"])
+    return out
+
+
+def _zeros(shape, device):
+    from .ops import fill_
+
+    return fill_(torch.empty(shape, dtype=torch.float32, device=device), 0.0)
+
+
 def read_flo(raw):
     """Middlebury .flo container (flownet2 flow_utils.readFlow; upstream source absent => file parse unpinned):
     float32 magic 202021.25, int32 width, int32 height, H*W*2 float32.  Returns a (H, W, 2) CPU tensor."""

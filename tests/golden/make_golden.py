@@ -399,6 +399,12 @@ def gen_dataprep(out):
                 f.write(np.float32(202021.25).tobytes() + np.int32(w).tobytes() + np.int32(h).tobytes() + flow.tobytes())
             ds.get_person_flow_path = lambda index: path
             ft, _ = td.TryonDataset.get_person_flow(ds, 0)
+        ds.cloth_mask_threshold = 240     # the reference's default (--cloth_mask_threshold, tryon_dataset.py:74-79)
+        cm_default = td.TryonDataset.get_input_cloth_mask(ds, im)
+        ds.cloth_mask_threshold = 0.25
+        cm_low = td.TryonDataset.get_input_cloth_mask(ds, im)
+        data[f"{tag}:cloth_mask_240"] = cm_default.numpy()
+        data[f"{tag}:cloth_mask_0.25"] = cm_low.numpy()
         data.update({f"{tag}:parse": parse, f"{tag}:image_u8": image, f"{tag}:keypoints": kp, f"{tag}:flow_payload": flow,
                      f"{tag}:image": im.numpy(), f"{tag}:im_head": head.numpy(), f"{tag}:im_cloth": cloth.numpy(),
                      f"{tag}:silhouette": sil.numpy(), f"{tag}:pose_map": pm.numpy(), f"{tag}:im_cocopose": vis.numpy(),

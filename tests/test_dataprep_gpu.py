@@ -144,3 +144,28 @@ def test_warp_test_step_to_disk_to_tryon_training_step(cuda, tmp_path):
         r = float(ref[k])
         assert abs(float(res.logs[k]) - r) <= 2e-5 + 2e-5 * abs(r), (k, float(res.logs[k]), r)
     assert float((unet.p_tryons[0].cpu() - ref["p_tryons"]).abs().max()) < 1e-4
+
+
+def test_build_batch_equals_the_reference_getitem_tensors(cuda):
+    """dataprep.build_batch - the tensor part of TryonDataset.__getitem__ for a whole batch on the GPU - against the
+    reference's own outputs (tests/golden/dataprep.npz), bit for bit, including the cloth mask (all ones with the reference's
+    default threshold) and the zeros the reference substitutes for missing optional files."""
+    from shineon_virtual_tryon_amd import dataprep
+
+    g = load_golden("dataprep.npz")
+    tag = "full"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)  # noqa: E731
+    parse, image_u8, kp, payload = (g[f"{tag}:{k}"] for k in ("parse", "image_u8", "keypoints", "flow_payload"))
+    raw = {"image_u8": dev(image_u8[None]), "cloth_u8": dev(image_u8[None]), "parse_u8": dev(parse[None]),
+           "keypoints": dev(kp[None]), "flow_payload": dev(payload[None])}
+    b = dataprep.build_batch(raw)
+    expect = {"image": "image", "cloth": "image", "im_head": "im_head", "im_cloth": "im_cloth", "silhouette": "silhouette",
+              "cocopose": "pose_map", "im_cocopose": "im_cocopose", "flow": "flow", "cloth_mask": "cloth_mask_240"}
+    for key, gk in expect.items():
+        np.testing.assert_array_equal(b[key][0].cpu().numpy(), g[f"{tag}:{gk}"], err_msg=key)
+    np.testing.assert_array_equal(b["agnostic"][0].cpu().numpy(), np.concatenate([g[f"{tag}:silhouette"], g[f"{tag}:im_head"]]))
+    assert float(b["prev_image"].abs().max()) == 0.0 and float(b["densepose"].abs().max()) == 0.0   # missing files -> zeros
+    low = dataprep.cloth_mask(b["cloth"], 0.25)
+    np.testing.assert_array_equal(low[0].cpu().numpy(), g[f"{tag}:cloth_mask_0.25"])
+    # the batch feeds the models: shapes / keys of the dict the reference's collate would hand to training_step
+    assert b["agnostic"].shape == (1, 4, 256, 192) and b["cocopose"].shape == (1, 18, 256, 192) and b["cloth_mask"].shape == (1, 1, 256, 192)

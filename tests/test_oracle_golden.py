@@ -214,6 +214,10 @@ def test_dataprep_oracle_bit_exact_vs_reference(tag):
     pm1, _ = dpo.pose_map(kp, h, w, 5, draw_into_map=True)
     np.testing.assert_array_equal(pm1, g[f"{tag}:pil_squares"].astype(np.float32) / 255 * 2 - 1)
     np.testing.assert_array_equal(dpo.flow_tensor(payload), g[f"{tag}:flow"])
+    # cloth mask: the reference thresholds the NORMALISED image with its 0-255 default (240) -> all ones; 0.25 shows the rule
+    np.testing.assert_array_equal(dpo.cloth_mask(im, 240), g[f"{tag}:cloth_mask_240"])
+    np.testing.assert_array_equal(dpo.cloth_mask(im, 0.25), g[f"{tag}:cloth_mask_0.25"])
+    assert float(g[f"{tag}:cloth_mask_240"].min()) == 1.0
     raw = np.float32(202021.25).tobytes() + np.int32(w).tobytes() + np.int32(h).tobytes() + payload.tobytes()
     np.testing.assert_array_equal(dpo.read_flo(raw), payload)
 
