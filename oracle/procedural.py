@@ -29,6 +29,11 @@ def procedural_tensor(key, shape, seed=420):
         return torch.full(shape, 0.7, dtype=torch.float32)
     if leaf == "bias":
         return torch.from_numpy(r.normal(0.0, 0.05, shape)).float()
+    if leaf in ("weight_u", "weight_v"):  # spectral norm's power-iteration vectors: unit length, NOT converged
+        x = r.normal(0.0, 1.0, shape)
+        return torch.from_numpy(x / np.linalg.norm(x)).float()
+    if leaf == "weight_orig":
+        leaf = "weight"
     if leaf == "weight" and len(shape) == 1:  # BatchNorm scale
         return torch.from_numpy(r.normal(1.0, 0.1, shape)).float()
     if leaf == "weight":
@@ -36,6 +41,8 @@ def procedural_tensor(key, shape, seed=420):
         std = (2.0 / fan_in) ** 0.5  # He: keeps 13 VGG layers / 12 U-Net layers in range
         if "linear" in key or "query_conv" in key or "key_conv" in key:
             std = 0.02  # the reference's own init scale; keeps the attention softmax soft (well conditioned)
+        if "mlp_gamma" in key or "mlp_beta" in key:
+            std *= 0.25  # SPADE modulation: up to 4 x (1 + gamma) factors per norm site, 2-3 sites per block
         return torch.from_numpy(r.normal(0.0, std, shape)).float()
     raise KeyError(f"no procedural rule for {key}")
 

@@ -425,6 +425,78 @@ def gen_dataprep(out):
     print("dataprep.npz", len(data), "arrays", os.path.getsize(os.path.join(out, "dataprep.npz")), "bytes")
 
 
+def sams_hparams(**kw):
+    """SamsModel options at a size the CPU finishes in seconds: 64 x 48 frames, 3 frames, features 8..32."""
+    base = dict(n_frames_total=3, n_frames_now=None, person_inputs=["agnostic", "densepose", "flow"], cloth_inputs=["cloth"],
+                encoder_input="flow", flow_warp=True, activation="relu", fine_height=64, fine_width=48,
+                norm_G="spectralspadesyncbatch3x3", ngf_base=2, ngf_pow_outer=3, ngf_pow_inner=5, ngf_pow_step=1, num_middle=2,
+                attention_middle_indices=[], attention_decoder_indices=[], init_type="xavier", init_variance=0.02,
+                netD_subarch="n_layer", num_D=2, n_layers_D=4, ndf=8, norm_D="spectralinstance", gan_mode="hinge", lr=1e-4,
+                lr_D=3e-4, no_ganFeat_loss=False, wt_l1=1.0, wt_vgg=1.0, wt_multiscale=1.0, wt_temporal=1.0)
+    base.update(kw)
+    return hp_namespace(**base)
+
+
+SAMS_VARIANTS = {
+    "base": dict(),
+    "attn_gelu": dict(attention_middle_indices=["0"], attention_decoder_indices=["-1"], activation="gelu", gan_mode="ls",
+                      norm_G="spectralspadebatch3x3"),
+    "progressive": dict(n_frames_total=4, n_frames_now=2, flow_warp=False, gan_mode="original", norm_G="spadeinstance3x3",
+                        norm_D="spectralbatch", no_ganFeat_loss=True, wt_l1=0.5, wt_vgg=2.0, wt_multiscale=0.25, wt_temporal=4.0),
+}
+
+
+def gen_sams(out):
+    """SAMS-GAN: the reference's SamsModel, three training steps in Lightning's order (generator,
+    multiscale discriminator, temporal discriminator) on procedural weights; every logged scalar, the generated frames,
+    the buffers the steps mutate and the gradients of each step's own parameter set."""
+    from models.sams_model import SamsModel
+
+    for tag, kw in SAMS_VARIANTS.items():
+        hp = sams_hparams(**kw)
+        torch.manual_seed(0)
+        model = SamsModel(hp)
+        model.load_state_dict(procedural_state_dict(shapes_of(model.state_dict())))
+        model.train()
+        batch = synthetic_batch(2, "cpu", height=hp.fine_height, width=hp.fine_width, n_frames=hp.n_frames_total, smooth=True)
+        data = {"state_keys": np.array(list(model.state_dict().keys())),
+                "state_shapes": np.array([str(tuple(v.shape)) for v in model.state_dict().values()])}
+        nets = {0: model.generator, 1: model.multiscale_discriminator, 2: model.temporal_discriminator}
+        for idx in (0, 1, 2):
+            # Lightning 0.9 with several optimizers: only the current optimizer's parameters require grad
+            for p in model.parameters():
+                p.requires_grad = False
+            for p in nets[idx].parameters():
+                p.requires_grad = True
+            model.zero_grad()
+            res = model.training_step(batch, 0, idx)
+            res.minimize.backward()
+            for k, v in res.logs.items():
+                data[f"log{idx}:" + k] = np.float64(v.item())
+            if idx == 0:
+                data["frames_s4"] = strided(model.all_gen_frames, 4)
+                data["frames_cs"] = checksums(model.all_gen_frames)
+            own = {0: "generator", 1: "multiscale_discriminator", 2: "temporal_discriminator"}[idx]
+            grads = {k: p.grad for k, p in nets[idx].named_parameters() if p.grad is not None}
+            for k, g in grads.items():
+                data[f"gcs{idx}:{own}.{k}"] = checksums(g)
+            # a few gradients in full: smallest tensors of the step plus the first conv
+            for k in sorted(grads, key=lambda k: grads[k].numel())[:6] + [next(iter(grads))]:
+                data[f"grad{idx}:{own}.{k}"] = grads[k].numpy()
+            # buffers after this step (u, v, running statistics): checksums of all, a few in full
+            for k, v in model.state_dict().items():
+                if k.startswith("criterion_VGG") or not v.is_floating_point():
+                    continue
+                if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+                    data[f"buf{idx}:{k}"] = checksums(v)
+        for k, v in model.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                data["nbt:" + k] = np.int64(v.item())
+        np.savez_compressed(os.path.join(out, f"sams_{tag}.npz"), **data)
+        print(f"sams_{tag}.npz", {k: float(v) for k, v in data.items() if k.startswith("log")},
+              os.path.getsize(os.path.join(out, f"sams_{tag}.npz")), "bytes")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shim()
@@ -441,3 +513,5 @@ if __name__ == "__main__":
         gen_init(HERE)
     if "dataprep" in which or not sys.argv[1:]:
         gen_dataprep(HERE)
+    if "sams" in which or not sys.argv[1:]:
+        gen_sams(HERE)
