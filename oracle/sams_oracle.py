@@ -87,16 +87,31 @@ def maybe_spectral_conv(sd, prefix, x, training, stride=1, padding=1):
     return F.conv2d(x, w, sd.get(prefix + ".bias"), stride=stride, padding=padding)
 
 
+def _moments(x, dims):
+    """Mean and biased variance over `dims`, accumulated in float64 and rounded to x.dtype: ATen's CPU batch / instance
+    norm kernels accumulate in `acc_type<float, false>` = double, and the goldens come from that code."""
+    xd = x.double()
+    mean = xd.mean(dim=dims, keepdim=True)
+    var = ((xd - mean) ** 2).mean(dim=dims, keepdim=True)
+    return mean.to(x.dtype), var.to(x.dtype)
+
+
+def instance_norm(x, eps=1e-5):
+    """nn.InstanceNorm2d(affine=False) (normalization.py:43, spade.py:47-48)."""
+    mean, var = _moments(x, (2, 3))
+    return (x - mean) / torch.sqrt(var + eps)
+
+
 def param_free_norm(sd, prefix, x, norm, training):
     """SPADE's parameter-free normalisation (sams/spade.py:65,80)."""
     if norm == "instance":
-        return base.instance_norm(x)
+        return instance_norm(x)
     rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
     if not training:
         return (x - rm[None, :, None, None]) / torch.sqrt(rv[None, :, None, None] + 1e-5)
     n = x.numel() / x.shape[1]
-    mean = x.mean(dim=(0, 2, 3))
-    var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+    mean, var = _moments(x, (0, 2, 3))
+    mean, var = mean.reshape(-1), var.reshape(-1)
     with torch.no_grad():
         rm.mul_(0.9).add_(0.1 * mean)
         rv.mul_(0.9).add_(0.1 * var * n / (n - 1))
@@ -236,7 +251,7 @@ def nlayer_discriminator(sd, prefix, x, hp, training):
             else:
                 x = maybe_spectral_conv(sd, f"{prefix}.model{n}.0.0", x, training, stride=stride, padding=2)
                 if subnorm == "instance":
-                    x = base.instance_norm(x)
+                    x = instance_norm(x)
                 elif subnorm in ("batch", "sync_batch"):
                     p = f"{prefix}.model{n}.0.1"
                     xn = param_free_norm(sd, p, x, "batch" if subnorm == "batch" else "syncbatch", training)
