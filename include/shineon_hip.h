@@ -339,6 +339,51 @@ int so_sb16_prep_weights(const float* w_ohwi, int Ko, int C, int Cw, int transpo
 int so_sb16_conv3x3(const void* xh, const void* xm, const void* wh, const void* wm, const float* bias, const float* gate,
                     float* y, int ldy, void* yh, void* ym, int Nb, int H, int W, int C, int Ko, int relu, void* stream);
 
+/* ---- SAMS-GAN (csrc/sams.hip) ------------------------------------------------------ */
+
+/* F.interpolate(mode="nearest") of the SPADE label maps (models/networks/sams/spade.py:83) and nn.Upsample(scale_factor=2 |
+ * 0.5) of the generator (models/networks/sams/sams_generator.py:294-308): y[ho][wo] = x[min(floor(ho * scale_h), Hi - 1)][..]
+ * with ATen's fp32 rule; scale = Hi / Ho for `size=`, 1 / scale_factor for `scale_factor=`.  _bwd is the adjoint
+ * (dx overwritten). */
+int so_resize_nearest_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int Hi, int Wi, int Ho, int Wo, int C,
+                          float scale_h, float scale_w, void* stream);
+int so_resize_nearest_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int Hi, int Wi, int Ho, int Wo, int C,
+                          float scale_h, float scale_w, void* stream);
+
+/* SPADE modulation (models/networks/sams/spade.py:89) fused with the activation AnySpadeResBlock applies to it
+ * (spade.py:168-169): y = act(nrm * (1 + gamma) + beta).  gamma / beta: [rows][C] each (two halves of one conv output
+ * are fine: same ld, pointers C apart).  _bwd recomputes the pre-activation and writes dn, dgamma, dbeta. */
+int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, float* y, int ldy,
+                 long long rows, int C, int act, float act_param, void* stream);
+int so_spade_bwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, const float* dy, int lddy,
+                 float* dn, int lddn, float* dgamma, int lddg, float* dbeta, int lddb, long long rows, int C, int act,
+                 float act_param, void* stream);
+
+/* F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False) between the scales of the multiscale discriminator
+ * (models/networks/discriminator.py:51-54): Ho = (H - 1) / 2 + 1. */
+int so_avgpool3s2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, void* stream);
+int so_avgpool3s2_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int H, int W, int C, void* stream);
+
+/* torch.nn.utils.spectral_norm (applied at models/networks/sams/spade.py:149-153 and models/networks/normalization.py:
+ * 24-25), dim 0, one power iteration: v <- normalize(W^T u), u <- normalize(W v), sigma = u^T W v, w_out = W / sigma.
+ * w_orig / w_out: dense OHWI [O][RS][I]; u: [O]; v: [I * RS] in torch's (I, R, S) flattening (checkpoint layout).
+ * power_iter = 0 (eval): u and v are only read.  sigma: 1 float, kept for the backward pass.
+ * _bwd: dw = g / sigma - (<g, W> / sigma^2) u v^T with the u, v of that forward (the caller keeps copies). */
+long long so_spectral_norm_ws_floats(int O, int I, int RS);
+int so_spectral_norm_fwd(const float* w_orig, int O, int I, int RS, float* u, float* v, float* w_out, float* sigma,
+                         int power_iter, float eps, float* ws, void* stream);
+int so_spectral_norm_bwd(const float* g, const float* w_orig, const float* u, const float* v, const float* sigma, int O,
+                         int I, int RS, float* dw, int accumulate, float* ws, void* stream);
+
+/* GANLoss.loss (models/networks/loss.py:58-88) with labels 1 / 0: mean over all elements of
+ * mode 0 "original": BCE with logits; 1 "ls": (x - t)^2; 2 "w": -x (real) / x (fake); 3 "hinge": -min(x - 1, 0) (real),
+ * -min(-x - 1, 0) (fake) for the discriminator, -x for the generator.  out: 1 float; ws: 1024 floats.
+ * _bwd: dx = gout[0] / count * f'(x). */
+int so_gan_loss_fwd(const float* x, int ldx, long long rows, int C, int mode, int target_is_real, int for_discriminator,
+                    float* out, float* ws, void* stream);
+int so_gan_loss_bwd(const float* x, int ldx, long long rows, int C, int mode, int target_is_real, int for_discriminator,
+                    const float* gout, float* dx, int lddx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,16 @@ from . import shineon_oracle as base
 
 CHANNELS = {"agnostic": 4, "cocopose": 18, "densepose": 3, "cloth": 3, "flow": 2, "image": 3}
 
+DEBUG_TAPS = None  # tools/ set this to a list to receive (name, tensor) for every intermediate of the SPADE blocks
+
+
+def _tap(name, t):
+    if DEBUG_TAPS is not None:
+        if t.requires_grad:
+            t.retain_grad()
+        DEBUG_TAPS.append((name, t))
+    return t
+
 
 # ------------------------------------------------------------------------------------------------
 # building blocks
@@ -123,14 +133,15 @@ def param_free_norm(sd, prefix, x, norm, training):
 def spade(sd, prefix, x, segmap, hp, training):
     """SPADE.forward (sams/spade.py:77-91)."""
     norm, ks = parse_spade_config(hp.norm_G.replace("spectral", ""))
-    normalized = param_free_norm(sd, prefix + ".param_free_norm", x, norm, training)
+    normalized = _tap(prefix + ":normalized", param_free_norm(sd, prefix + ".param_free_norm", x, norm, training))
     seg = F.interpolate(segmap, size=x.shape[2:], mode="nearest")
     pw = ks // 2
     actv = spade_activation(F.conv2d(seg, sd[prefix + ".mlp_shared.0.weight"], sd[prefix + ".mlp_shared.0.bias"], padding=pw),
                             hp.activation)
-    gamma = F.conv2d(actv, sd[prefix + ".mlp_gamma.weight"], sd[prefix + ".mlp_gamma.bias"], padding=pw)
-    beta = F.conv2d(actv, sd[prefix + ".mlp_beta.weight"], sd[prefix + ".mlp_beta.bias"], padding=pw)
-    return normalized * (1 + gamma) + beta
+    _tap(prefix + ":actv", actv)
+    gamma = _tap(prefix + ":gamma", F.conv2d(actv, sd[prefix + ".mlp_gamma.weight"], sd[prefix + ".mlp_gamma.bias"], padding=pw))
+    beta = _tap(prefix + ":beta", F.conv2d(actv, sd[prefix + ".mlp_beta.weight"], sd[prefix + ".mlp_beta.bias"], padding=pw))
+    return _tap(prefix + ":out", normalized * (1 + gamma) + beta)
 
 
 def multispade(sd, prefix, x, labelmaps, hp, training):
@@ -203,8 +214,16 @@ def generator_layout(hp):
     return enc, list(range(hp.num_middle)), dec
 
 
-def generator_forward(sd, prev_frames, prev_labelmaps, current_labelmaps, hp, training, prefix="generator"):
-    """SamsGenerator.forward (sams_generator.py:240-291).  prev_frames / prev_labelmaps: (b, n-1, c, h, w)."""
+def generator_forward(sd, prev_frames, prev_labelmaps, current_labelmaps, hp, training, prefix="generator", taps=None):
+    """SamsGenerator.forward (sams_generator.py:240-291).  prev_frames / prev_labelmaps: (b, n-1, c, h, w).
+    taps: optional list that receives (name, activation) after every layer (tests localise a mismatch with it)."""
+    def tap(name, t):
+        if taps is not None:
+            if t.requires_grad:
+                t.retain_grad()
+            taps.append((name, t))
+        return t
+
     b, n, c, h, w = prev_frames.shape
     x = prev_frames.reshape(b, n * c, h, w)
     prev_maps = prev_labelmaps.reshape(b, -1, h, w)
@@ -216,8 +235,9 @@ def generator_forward(sd, prev_frames, prev_labelmaps, current_labelmaps, hp, tr
             x = spade_resblock(sd, f"{prefix}.encode_layers.{i}", x, prev_maps, hp, training)
         else:  # nn.Upsample(scale_factor=0.5), default mode "nearest" (sams_generator.py:299)
             x = F.interpolate(x, scale_factor=0.5, mode="nearest")
+        tap(f"encode_layers.{i}", x)
     for i in mid:
-        x = spade_resblock(sd, f"{prefix}.middle_layers.{i}", x, current_labelmaps, hp, training)
+        x = tap(f"middle_layers.{i}", spade_resblock(sd, f"{prefix}.middle_layers.{i}", x, current_labelmaps, hp, training))
     for kind, i in dec:
         if kind == "conv":
             x = F.conv2d(x, sd[f"{prefix}.decode_layers.{i}.weight"], sd[f"{prefix}.decode_layers.{i}.bias"], padding=1)
@@ -225,6 +245,7 @@ def generator_forward(sd, prev_frames, prev_labelmaps, current_labelmaps, hp, tr
             x = spade_resblock(sd, f"{prefix}.decode_layers.{i}", x, current_labelmaps, hp, training)
         else:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
+        tap(f"decode_layers.{i}", x)
     return x
 
 

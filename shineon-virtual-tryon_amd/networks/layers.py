@@ -23,11 +23,15 @@ def _ohwi_param(o, i, r, s):
 class HipConv2d(nn.Module):
     """nn.Conv2d(in, out, k, stride, padding, bias) replacement (zero padding, dilation 1, groups 1)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, fuse_relu=False):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, fuse_relu=False,
+                 fuse_leaky=None):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.fuse_relu = fuse_relu
+        # fuse_leaky = slope: LeakyReLU(slope) in the convolution's epilogue (PatchGAN layers, discriminator.py:108-111)
+        self.fused_act = ops.ACT_RELU if fuse_relu else (ops.ACT_LEAKY if fuse_leaky is not None else ops.ACT_NONE)
+        self.fused_act_param = float(fuse_leaky) if fuse_leaky is not None else 0.0
         # Set by the owning block when this conv feeds an Instance/BatchNorm directly: the bias gradient is then
         # analytically zero (the norm removes per-channel constants) and its reduction is skipped.
         # "always": InstanceNorm follows; "train": BatchNorm follows (true only with batch statistics).
@@ -47,8 +51,8 @@ class HipConv2d(nn.Module):
 
     def forward(self, x):
         zbg = self.zero_bias_grad == "always" or (self.zero_bias_grad == "train" and self.training)
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding,
-                          ops.ACT_RELU if self.fuse_relu else ops.ACT_NONE, zero_bias_grad=zbg)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.fused_act, zero_bias_grad=zbg,
+                          act_param=self.fused_act_param)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -67,14 +71,21 @@ class HipInstanceNorm2d(nn.Module):
 
 
 class HipBatchNorm2d(nn.Module):
-    """nn.BatchNorm2d(C): batch statistics in training (running stats updated with momentum 0.1 and the
-    unbiased variance), running statistics in eval."""
+    """nn.BatchNorm2d(C, affine=...): batch statistics in training (running stats updated with momentum 0.1 and the
+    unbiased variance), running statistics in eval.  count_batches=False reproduces a bare F.batch_norm call, which
+    updates the running statistics but not num_batches_tracked (the reference's SynchronizedBatchNorm2d outside
+    DataParallelWithCallback, models/networks/sync_batchnorm/batchnorm.py:63-68)."""
 
-    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, count_batches=True):
         super().__init__()
         self.num_features, self.eps, self.momentum = num_features, eps, momentum
-        self.weight = nn.Parameter(torch.ones(num_features))
-        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.affine, self.count_batches = affine, count_batches
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
@@ -84,7 +95,7 @@ class HipBatchNorm2d(nn.Module):
         """relu_gate_input (training only): x is a ReLU output whose producer leaves the ReLU's backward mask to this
         layer (see ops.batch_norm_train)."""
         if self.training:
-            if not self._shared_counter:
+            if self.count_batches and not self._shared_counter:
                 self.num_batches_tracked += 1
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.momentum, self.eps, relu_gate_input=relu_gate_input)

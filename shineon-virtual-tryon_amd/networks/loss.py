@@ -1,10 +1,39 @@
 """Perceptual loss (reference: models/networks/loss.py:106-122): sum_i w_i * mean|vgg_i(x) - vgg_i(y)|
-with w = (1/32, 1/16, 1/8, 1/4, 1), target branch detached.  GANLoss is SAMS-only and out of scope."""
+with w = (1/32, 1/16, 1/8, 1/4, 1), target branch detached; and the SAMS-GAN's adversarial loss (loss.py:13-103)."""
 import torch
 from torch import nn
 
-from .. import ops
+from .. import ops, ops_sams
 from .vgg import Vgg19
+
+
+class GANLoss(nn.Module):
+    """LSGAN / cross-entropy / Wasserstein / hinge objective on discriminator predictions (loss.py:13-103) with the
+    default labels (real 1, fake 0).  A list of predictions is averaged over its entries — an entry that is itself a
+    list (one discriminator's stage outputs) contributes its LAST element — and the list branch returns shape (1,),
+    like the reference."""
+
+    AVAILABLE_MODES = ("ls", "original", "w", "hinge")
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=None, opt=None):
+        super().__init__()
+        assert gan_mode in GANLoss.AVAILABLE_MODES, f"Unexpected gan_mode = {gan_mode}"
+        if (target_real_label, target_fake_label) != (1.0, 0.0):
+            raise NotImplementedError("GANLoss labels other than 1.0 / 0.0 (the reference never passes any)")
+        self.gan_mode, self.opt = gan_mode, opt
+
+    def loss(self, input, target_is_real, for_discriminator=True):
+        return ops_sams.gan_loss(input, self.gan_mode, target_is_real, for_discriminator)
+
+    def __call__(self, input, target_is_real, for_discriminator=True):
+        if isinstance(input, list):
+            total = 0
+            for pred in input:
+                if isinstance(pred, list):
+                    pred = pred[-1]
+                total = total + self.loss(pred, target_is_real, for_discriminator).reshape(1)
+            return total / len(input)
+        return self.loss(input, target_is_real, for_discriminator)
 
 
 class VGGLoss(nn.Module):

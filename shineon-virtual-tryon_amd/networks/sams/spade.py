@@ -1,0 +1,94 @@
+"""SPADE and the SPADE residual block of the SAMS generator (reference: models/networks/sams/spade.py).
+
+Module tree (state_dict keys) as in the reference: `param_free_norm`, `mlp_shared.0`, `mlp_gamma`, `mlp_beta`;
+`conv_0 / conv_1 / conv_s`, `spade_0 / spade_1 / norm_s`.  Execution differs: mlp_gamma and mlp_beta read the same
+activation, so they run as ONE convolution with stacked weights, and the modulation `n * (1 + gamma) + beta` is a
+single pass that also applies the residual block's activation when one follows.
+"""
+import re
+
+from torch import nn
+
+from ... import ops, ops_sams
+from ..layers import HipBatchNorm2d, HipConv2d, HipInstanceNorm2d
+from ..spectral import spectral_norm
+from ..sync_batchnorm import SynchronizedBatchNorm2d
+
+# activation names -> op codes.  The SPADE MLP reads "relu" as a true ReLU (spade.py:93-103), the residual block as
+# LeakyReLU(0.2) (spade.py:182-192).
+_MLP_ACT = {"relu": ("relu", 0.0), "gelu": ("gelu", 0.0), "swish": ("swish", 0.0), "sine": ("sine", 0.0)}
+_BLOCK_ACT = {"relu": ("leaky", 0.2), "gelu": ("gelu", 0.0), "swish": ("swish", 0.0), "sine": ("sine", 0.0)}
+
+
+def _lookup(table, name):
+    if name not in table:
+        raise RuntimeError(f"The selected activation should be relu/gelu/swish/sine, not {name}")
+    return table[name]
+
+
+class SPADE(nn.Module):
+    @staticmethod
+    def parse_config_text(config_text):
+        """"spade<norm><k>x<k>" -> (parameter-free norm class, kernel size) (spade.py:36-59)."""
+        assert config_text.startswith("spade")
+        parsed = re.search(r"spade(\D+)(\d)x\d", config_text)
+        kind = str(parsed.group(1))
+        norms = {"instance": HipInstanceNorm2d, "syncbatch": SynchronizedBatchNorm2d, "batch": HipBatchNorm2d}
+        if kind not in norms:
+            raise ValueError("%s is not a recognized param-free norm type in SPADE" % kind)
+        return norms[kind], int(parsed.group(2))
+
+    def __init__(self, config_text, norm_nc, label_nc, activation):
+        super().__init__()
+        norm_cls, ks = SPADE.parse_config_text(config_text)
+        self.param_free_norm = norm_cls(norm_nc) if norm_cls is HipInstanceNorm2d else norm_cls(norm_nc, affine=False)
+        self.mlp_act = _lookup(_MLP_ACT, activation)
+        self.nhidden = nhidden = 128  # hard-coded in the reference (spade.py:68)
+        pw = ks // 2
+        fuse = self.mlp_act[0] == "relu"
+        # index 0 keeps the reference's nn.Sequential(conv, activation) key `mlp_shared.0`
+        self.mlp_shared = nn.ModuleList([HipConv2d(label_nc, nhidden, ks, padding=pw, fuse_relu=fuse)])
+        self.mlp_gamma = HipConv2d(nhidden, norm_nc, ks, padding=pw)
+        self.mlp_beta = HipConv2d(nhidden, norm_nc, ks, padding=pw)
+
+    def forward(self, x, segmap, then_act=None):
+        """then_act: (kind, param) of an activation applied to the result in the same pass."""
+        normalized = self.param_free_norm(x)
+        seg = ops_sams.resize_nearest(segmap, size=x.shape[2:])
+        actv = self.mlp_shared[0](seg)
+        if self.mlp_act[0] != "relu":
+            actv = ops.activation(actv, *self.mlp_act)
+        w2, b2 = ops_sams.stack_conv_params(self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
+        gamma_beta = ops.conv2d(actv, w2, b2, 1, self.mlp_gamma.padding)
+        kind, param = then_act if then_act is not None else ("none", 0.0)
+        return ops_sams.spade_modulate(normalized, gamma_beta, kind, param)
+
+
+class AnySpadeResBlock(nn.Module):
+    """norm -> activation -> conv, twice, plus a (learned, if the channel count changes) shortcut (spade.py:106-180)."""
+
+    def __init__(self, fin, fout, norm_G, label_channels, spade_class, activation):
+        super().__init__()
+        self.learned_shortcut = fin != fout
+        fmiddle = min(fin, fout)
+        self.conv_0 = HipConv2d(fin, fmiddle, 3, padding=1)
+        self.conv_1 = HipConv2d(fmiddle, fout, 3, padding=1)
+        if self.learned_shortcut:
+            self.conv_s = HipConv2d(fin, fout, 1, padding=0, bias=False)
+        if "spectral" in norm_G:
+            self.conv_0 = spectral_norm(self.conv_0)
+            self.conv_1 = spectral_norm(self.conv_1)
+            if self.learned_shortcut:
+                self.conv_s = spectral_norm(self.conv_s)
+        config = norm_G.replace("spectral", "")
+        self.spade_0 = spade_class(config, fin, label_channels, activation)
+        self.spade_1 = spade_class(config, fmiddle, label_channels, activation)
+        if self.learned_shortcut:
+            self.norm_s = spade_class(config, fin, label_channels, activation)
+        self.block_act = _lookup(_BLOCK_ACT, activation)
+
+    def forward(self, x, seg):
+        x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
+        dx = self.conv_0(self.spade_0(x, seg, then_act=self.block_act))
+        dx = self.conv_1(self.spade_1(dx, seg, then_act=self.block_act))
+        return ops.add(x_s, dx)

@@ -300,8 +300,11 @@ class _Conv2dFn(torch.autograd.Function):
     channels are computed as op = ceil4(o) columns of which the last op - o are exactly zero."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False):
+    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0):
         L = lib()
+        if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+            # the backward pass evaluates act' from the OUTPUT, which only sign-preserving piecewise-linear maps allow
+            raise ValueError("conv2d fuses ReLU / LeakyReLU only")
         o, i, r, s = weight.shape
         cp, op = (i + 3) // 4 * 4, (o + 3) // 4 * 4
         xr = to_rows(x, cpad=cp) if cp != i else _dense_rows(x)
@@ -314,7 +317,7 @@ class _Conv2dFn(torch.autograd.Function):
         check(
             L.so_conv2d_fprop_padded(
                 xr.data_ptr(), _ld(xr), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                y.data_ptr(), op, n, h, wd, cp, op, o, r, s, stride, pad, act, 0.0,
+                y.data_ptr(), op, n, h, wd, cp, op, o, r, s, stride, pad, act, float(act_param),
                 ws.data_ptr(), ws.numel() * 4, _stream(),
             ),
             "conv2d_fprop",
@@ -322,7 +325,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(xr, w, y if act != ACT_NONE and not act_grad_external else None)
         # act_grad_external: the consumer (a BatchNorm told so) applies the activation's mask to the gradient it sends
         ctx.cfg = (stride, pad, ACT_NONE if act_grad_external else act, i, cp, op, bias is not None, tuple(weight.shape),
-                   zero_bias_grad)
+                   zero_bias_grad, float(act_param))
         # parameters whose .grad is a view of the optimizer's flat slab get their gradient accumulated in place
         ctx.direct = (weight if _direct_grad_ok(weight, ohwi=True) else None,
                       bias if bias is not None and _direct_grad_ok(bias, ohwi=False) else None)
@@ -332,7 +335,7 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = lib()
         xr, w, y = ctx.saved_tensors
-        stride, pad, act, i, cp, op, has_bias, wshape, zero_bias_grad = ctx.cfg
+        stride, pad, act, i, cp, op, has_bias, wshape, zero_bias_grad, act_param = ctx.cfg
         o, _, r, s = wshape
         n, _, h, wd = xr.shape
         dy = to_rows(dy, cpad=op) if op != o else _dense_rows(dy)  # [rows][op], pad columns zero
@@ -340,7 +343,7 @@ class _Conv2dFn(torch.autograd.Function):
         rows_out = dy.shape[0] * dy.shape[2] * dy.shape[3]
         if act != ACT_NONE:
             g = nhwc_empty(dy.shape[0], dy.shape[2], dy.shape[3], op, dev)
-            check(L.so_act_bwd(y.data_ptr(), op, dy.data_ptr(), _ld(dy), g.data_ptr(), op, rows_out, op, act, 0.0, _stream()), "act_bwd")
+            check(L.so_act_bwd(y.data_ptr(), op, dy.data_ptr(), _ld(dy), g.data_ptr(), op, rows_out, op, act, act_param, _stream()), "act_bwd")
             dy = g
         dx = dw = db = None
         w_direct, b_direct = ctx.direct
@@ -424,15 +427,16 @@ class _Conv2dFn(torch.autograd.Function):
             fork.join()
         elif need_w or need_b:
             dw, db = weight_grads(lane=0)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False):
+def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False,
+           act_param=0.0):
     """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
     output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
     act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
     (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel."""
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -464,6 +468,29 @@ def activation(x, kind, param=0.0):
     return _ActFn.apply(x, ACT_CODES[kind] if not isinstance(kind, int) else kind, float(param))
 
 
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        L = lib()
+        a, b = to_rows(a), to_rows(b)
+        n, c, h, w = a.shape
+        out = nhwc_empty(n, h, w, c, a.device)
+        check(L.so_copy2d(a.data_ptr(), _ld(a), c, out.data_ptr(), c, c, n * h * w, 0, _stream()), "copy2d")
+        check(L.so_copy2d(b.data_ptr(), _ld(b), c, out.data_ptr(), c, c, n * h * w, 1, _stream()), "copy2d")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    """a + b of two same-shape activations (residual connections, sams/spade.py:171)."""
+    if a.shape != b.shape:
+        raise ValueError(f"add: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    return _AddFn.apply(a, b)
+
+
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -493,6 +520,35 @@ class _CatFn(torch.autograd.Function):
 def cat_channels(xs):
     """torch.cat(xs, dim=1) for NHWC-pitch tensors (gradient = channel slices, no copy)."""
     return _CatFn.apply(*xs)
+
+
+class _CatBatchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        L = lib()
+        xs = [to_rows(x) for x in xs]
+        _, c, h, w = xs[0].shape
+        ns = [x.shape[0] for x in xs]
+        out = nhwc_empty(sum(ns), h, w, c, xs[0].device)
+        row = 0
+        for x, n in zip(xs, ns):
+            check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * row * c, c, c, n * h * w, 0, _stream()), "copy2d")
+            row += n * h * w
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, k = [], 0
+        for n in ctx.ns:
+            outs.append(dy[k:k + n])
+            k += n
+        return tuple(outs)
+
+
+def cat_batch(xs):
+    """torch.cat(xs, dim=0) of NHWC-pitch activations (sams_model.py:397: fake and real halves of a discriminator batch)."""
+    return _CatBatchFn.apply(*xs)
 
 
 class _Upsample2xFn(torch.autograd.Function):
@@ -665,7 +721,8 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):
     y = nhwc_empty(n, h, w, c, x.device)
     check(
         lib().so_norm_apply(x.data_ptr(), _ld(x), y.data_ptr(), c, 1, n * h * w, c, running_mean.data_ptr(),
-                            running_var.data_ptr(), 1, eps, gamma.data_ptr(), beta.data_ptr(), _stream()),
+                            running_var.data_ptr(), 1, eps, gamma.data_ptr() if gamma is not None else None,
+                            beta.data_ptr() if beta is not None else None, _stream()),
         "norm_apply",
     )
     return y

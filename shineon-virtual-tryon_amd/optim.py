@@ -49,6 +49,8 @@ class HipAdam(torch.optim.Optimizer):
             view.copy_(p.data)
             p.data = view
             gview = torch.as_strided(flat_g, p.shape, view.stride(), off)
+            if p.grad is not None:  # built lazily after a first backward: keep what autograd already produced
+                gview.copy_(p.grad)
             p.grad = gview
             p._so_grad_direct = True  # ops.py may accumulate wgrad / bias-grad kernels straight into this view
             self._slots.append((p, off, view.data_ptr(), gview.data_ptr()))

@@ -15,9 +15,11 @@ def find_model_using_name(model_name):
         from . import warp_model as lib
     elif model_name == "unet_mask":
         from . import unet_mask_model as lib
+    elif model_name == "sams":
+        from . import sams_model as lib
     else:
         raise NotImplementedError(
-            f"model '{model_name}' is outside the MI355X hot path (warp / unet_mask); see DESIGN.md"
+            f"model '{model_name}' is outside the MI355X hot path (warp / unet_mask / sams); see DESIGN.md"
         )
     target = model_name.replace("_", "") + "model"
     for name, cls in lib.__dict__.items():

@@ -372,6 +372,59 @@ class ChainedTrainStep:
 
 
 # ---- data: the dataset resident in HBM ----------------------------------------------------------------------------------
+class MultiOptimizerStep:
+    """One training batch of a model with SEVERAL optimizers, the way pytorch-lightning 0.9 drives it (the reference's
+    SamsModel returns three from configure_optimizers, models/sams_model.py:130-145): for each optimizer in turn —
+    only that optimizer's parameters require grad (Lightning toggles this so that a step never leaves gradients in the
+    other networks), `training_step(batch, batch_idx, optimizer_idx)`, backward, gradient mean over the ranks,
+    optimizer step, zero_grad.  Runs eagerly: the generator pass is five dependent forward passes whose launch count
+    dwarfs a hipGraph's benefit only at toy sizes."""
+
+    def __init__(self, model, optimizers, networks=None, accumulate=1):
+        self.model, self.optimizers = model, list(optimizers)
+        self.networks = list(networks) if networks is not None else model.optimizer_networks()
+        if len(self.networks) != len(self.optimizers):
+            raise ValueError("one network per optimizer")
+        self.accumulate = max(1, accumulate)
+        self._micro = 0
+        self._all = [p for p in model.parameters()]
+        self._frozen = [p for p in self._all if not p.requires_grad]  # e.g. the VGG of the perceptual loss: never toggled on
+        self._own = [[p for p in net.parameters()] for net in self.networks]
+        flats = [o.flat_grads for o in self.optimizers]  # builds the slabs now: backward then accumulates straight into them
+        self.reducers = [GradientAllReducer(f) for f in flats] if _world() > 1 else None
+        self.stepped = False
+
+    def _only(self, idx):
+        for p in self._all:
+            p.requires_grad_(False)
+        for p in self._own[idx]:
+            p.requires_grad_(True)
+
+    def restore_requires_grad(self):
+        frozen = {id(p) for p in self._frozen}
+        for p in self._all:
+            p.requires_grad_(id(p) not in frozen)
+
+    def __call__(self, batch, batch_idx=0):
+        results = []
+        self._micro += 1
+        update = self._micro % self.accumulate == 0
+        for idx, opt in enumerate(self.optimizers):
+            self._only(idx)
+            result = self.model.training_step(batch, batch_idx, idx)
+            result.minimize.sum().backward()
+            if update:
+                scale = self.reducers[idx].all_reduce() if self.reducers is not None else 1.0
+                opt.step(grad_scale=scale / self.accumulate)
+                opt.zero_grad()
+            results.append(result)
+        self.stepped = update
+        return results
+
+    def flush(self):
+        pass
+
+
 class DeviceBatches:
     """A map-style dataset collated ONCE and kept resident in HBM (288 GB: the synthetic VVT-shaped set is 9.4 MB per
     sample); batches are gathered by index on the device, so the input side costs one small kernel per batch key instead
@@ -446,6 +499,7 @@ class Trainer:
         self.global_step = 0
         self.current_epoch = 0
         self.model = self.optimizer = self.scheduler = None
+        self.optimizers, self.schedulers = [], []
         self._interrupted = False
         self.epoch_seconds = []
 
@@ -461,8 +515,8 @@ class Trainer:
         torch.save({
             "state_dict": {k: v.detach().cpu().contiguous() for k, v in self.model.state_dict().items()},
             "hparams": hp, "hyper_parameters": hp,
-            "optimizer_states": [self.optimizer.state_dict()] if self.optimizer else [],
-            "lr_schedulers": [self.scheduler.state_dict()] if self.scheduler else [],
+            "optimizer_states": [o.state_dict() for o in self.optimizers],
+            "lr_schedulers": [sc.state_dict() for sc in self.schedulers],
             "global_step": self.global_step, "epoch": self.current_epoch + (1 if epoch_finished else 0),
             "vgg_pretrained": _vgg_flag(self.model),
         }, path)
@@ -481,16 +535,17 @@ class Trainer:
             vgg.pretrained_loaded = bool(ckpt.get("vgg_pretrained", True))
         self.global_step = int(ckpt.get("global_step", 0))
         self.current_epoch = int(ckpt.get("epoch", 0))
-        if ckpt.get("optimizer_states") and self.optimizer is not None:
-            self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
-        if self.scheduler is not None:
-            if ckpt.get("lr_schedulers"):
-                self.scheduler.load_state_dict(dict(ckpt["lr_schedulers"][0]))
+        states, scheds = ckpt.get("optimizer_states") or [], ckpt.get("lr_schedulers") or []
+        for k, (optimizer, scheduler) in enumerate(zip(self.optimizers, self.schedulers)):
+            if k < len(states):
+                optimizer.load_state_dict(states[k])
+            if k < len(scheds):
+                scheduler.load_state_dict(dict(scheds[k]))
             else:  # older checkpoint: put the schedule at the epoch we resume with
-                self.scheduler.last_epoch = self.current_epoch
-            for group, lam, base in zip(self.optimizer.param_groups, self.scheduler.lr_lambdas, self.scheduler.base_lrs):
-                group["lr"] = base * lam(self.scheduler.last_epoch)
-            self.scheduler._last_lr = [g["lr"] for g in self.optimizer.param_groups]
+                scheduler.last_epoch = self.current_epoch
+            for group, lam, base in zip(optimizer.param_groups, scheduler.lr_lambdas, scheduler.base_lrs):
+                group["lr"] = base * lam(scheduler.last_epoch)
+            scheduler._last_lr = [g["lr"] for g in optimizer.param_groups]
 
     def _limit(self, n, lim):
         lim = str2num(str(lim))
@@ -519,11 +574,14 @@ class Trainer:
         model.trainer = self
         model.prepare_data()
         model.setup("fit")
-        (self.optimizer,), (self.scheduler,) = model.configure_optimizers()
+        self.optimizers, self.schedulers = (list(x) for x in model.configure_optimizers())
+        self.optimizer, self.scheduler = self.optimizers[0], self.schedulers[0]
+        multi = len(self.optimizers) > 1
         self._maybe_resume()
         if hasattr(model, "require_pretrained_vgg"):
             model.require_pretrained_vgg()  # after the resume: a checkpoint brings its own criterionVGG.* weights
-        broadcast_parameters(model, optimizer=self.optimizer)
+        for optimizer in self.optimizers:
+            broadcast_parameters(model, optimizer=optimizer)
         train_loader, val_loader = self._loaders(model)
         ckpt_dir = osp.join(self.root, "checkpoints")
         previous = signal.signal(signal.SIGINT, self._on_sigint)
@@ -544,10 +602,12 @@ class Trainer:
                         break
                     batch = _to_device(batch, self.device)
                     model.global_step = self.global_step
-                    if step is None:
+                    if step is None and multi:
+                        step = MultiOptimizerStep(model, self.optimizers, accumulate=self.accumulate)
+                    elif step is None:
                         step = TrainStep(model, self.optimizer, batch, graph=self.graph, overlap=self.overlap,
                                          accumulate=self.accumulate, sync_buffers=self.broadcast_bn_buffers)
-                    self.last_result = step(batch)
+                    self.last_result = step(batch, i) if multi else step(batch)
                     if step.stepped:
                         self.global_step += 1
                         if self.global_step % self.save_count == 0:
@@ -565,7 +625,8 @@ class Trainer:
                     step.flush()
                 torch.cuda.synchronize()   # once per epoch: wall time of the epoch for throughput reports
                 self.epoch_seconds.append(time.perf_counter() - t_epoch)
-                self.scheduler.step()
+                for scheduler in self.schedulers:
+                    scheduler.step()
         except KeyboardInterrupt:
             raise SystemExit(130)
         except Exception as e:  # mirror train.py:63-66: checkpoint, then re-raise

@@ -1,6 +1,7 @@
 """Shared by the SAMS-GAN tests: the option sets of the committed goldens (tests/golden/make_golden.py::SAMS_VARIANTS),
 and the three training steps run through the oracle in Lightning's order."""
 import argparse
+import contextlib
 import os
 
 import numpy as np
@@ -38,6 +39,44 @@ def golden_shapes(g):
 
 
 STEP_NETS = ("generator", "multiscale_discriminator", "temporal_discriminator")
+
+
+@contextlib.contextmanager
+def kink_shift(delta_rel):
+    """Move the kink of every ReLU / LeakyReLU the oracle evaluates from 0 to delta_rel * max|x| (either sign).
+
+    Two fp32 implementations agree on a pre-activation to ~1e-6 of its tensor's magnitude; an element that close to 0
+    can land on either side of the kink, and its whole gradient contribution changes by the slope difference.  Running
+    the fp64 oracle with the kink shifted by +-delta brackets every such element: the spread of the resulting
+    gradients is what any correct fp32 implementation may differ by, and it is exactly 0 when no element is that close."""
+    import torch.nn.functional as F
+
+    relu, leaky = F.relu, F.leaky_relu
+
+    def shifted_relu(x, inplace=False):
+        return torch.where(x > delta_rel * x.detach().abs().max(), x, torch.zeros_like(x))
+
+    def shifted_leaky(x, negative_slope=0.01, inplace=False):
+        return torch.where(x > delta_rel * x.detach().abs().max(), x, negative_slope * x)
+
+    F.relu, F.leaky_relu = shifted_relu, shifted_leaky
+    try:
+        yield
+    finally:
+        F.relu, F.leaky_relu = relu, leaky
+
+
+def kink_spread(sd, hp, batch, exact_steps, delta_rel=3e-6):
+    """Per step: {key: max |gradient(kink at +-delta) - gradient(kink at 0)|} from two more fp64 oracle runs."""
+    spread = [dict() for _ in exact_steps]
+    for sign in (+1.0, -1.0):
+        with kink_shift(sign * delta_rel):
+            steps, _, _ = oracle_three_steps(sd, hp, batch, torch.float64)
+        for idx, (_, grads) in enumerate(steps):
+            for k, g in grads.items():
+                d = (g - exact_steps[idx][1][k]).abs().max().item()
+                spread[idx][k] = max(spread[idx].get(k, 0.0), d)
+    return spread
 
 
 def oracle_three_steps(sd, hp, batch, dtype=torch.float32):
