@@ -497,6 +497,31 @@ def gen_sams(out):
               os.path.getsize(os.path.join(out, f"sams_{tag}.npz")), "bytes")
 
 
+def gen_sams_init(out):
+    """BaseNetwork.init_weights (models/networks/base_network.py:42-77) under a fixed seed on the reference's own SAMS
+    networks: every parameter after the call (the draw order covers the double initialisation of the sub-discriminators
+    and the spectral-norm alias `module.weight` -> `weight_orig`)."""
+    from models.networks import MultiscaleDiscriminator, NLayerDiscriminator
+    from models.networks.sams.sams_generator import SamsGenerator
+
+    data = {}
+    for tag, kw in (("xavier", dict()), ("normal_batchD", dict(norm_D="spectralbatch", init_type="normal")),
+                    ("kaiming_attn", dict(init_type="kaiming", attention_middle_indices=["0"], norm_G="spadeinstance3x3"))):
+        hp = sams_hparams(**kw)
+        torch.manual_seed(99)
+        nets = {"G": SamsGenerator(hp), "Dm": MultiscaleDiscriminator(hp), "Dt": NLayerDiscriminator(hp, in_channels=15)}
+        torch.manual_seed(1234)
+        for name, net in nets.items():
+            net.init_weights(hp.init_type, hp.init_variance)
+            for k, p in net.named_parameters():
+                data[f"{tag}:{name}.{k}"] = checksums(p)
+            k0, p0 = next(iter(net.named_parameters()))
+            data[f"{tag}:full:{name}.{k0}"] = p0.detach().numpy()
+        data[f"{tag}:next_random"] = torch.rand(4).numpy()  # the generator's position after everything was drawn
+    np.savez_compressed(os.path.join(out, "sams_init.npz"), **data)
+    print("sams_init.npz", len(data), "arrays", os.path.getsize(os.path.join(out, "sams_init.npz")), "bytes")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     install_shim()
@@ -515,3 +540,5 @@ if __name__ == "__main__":
         gen_dataprep(HERE)
     if "sams" in which or not sys.argv[1:]:
         gen_sams(HERE)
+    if "sams_init" in which or not sys.argv[1:]:
+        gen_sams_init(HERE)

@@ -73,8 +73,11 @@ def test_registry():
 
     assert find_model_using_name("warp") is WarpModel and find_model_using_name("gmm") is WarpModel
     assert find_model_using_name("unet_mask") is UnetMaskModel and find_model_using_name("tom") is UnetMaskModel
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+
+    assert find_model_using_name("sams") is SamsModel
     with pytest.raises(NotImplementedError):
-        find_model_using_name("sams")
+        find_model_using_name("pix2pix")
 
 
 @pytest.mark.parametrize("name,kw", [("warp_model.npz", dict(person_inputs=["agnostic", "cocopose"])),
@@ -307,3 +310,128 @@ def test_init_weights_rules_on_the_gmm_networks():
     assert torch.equal(fr.conv[1].weight, torch.ones(512))
     with pytest.raises(NotImplementedError):
         init_weights(fr, "orthogonal")
+
+
+# ------------------------------------------------------------------------------------------------
+# SAMS-GAN host side
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["base", "attn_gelu", "progressive"])
+def test_sams_state_dict_layout_is_the_references(tag):
+    """Keys, their ORDER (spectral norm re-registers the weight after the bias) and shapes of SamsModel's state_dict equal
+    what the reference's SamsModel produced for the same options (tests/golden/sams_*.npz), so checkpoints interchange."""
+    import sams_helpers as sh
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+
+    g = sh.load_golden(tag)
+    model = SamsModel(sh.sams_hparams(**sh.SAMS_VARIANTS[tag]))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
+    shapes = sh.golden_shapes(g)
+    assert all(tuple(v.shape) == shapes[k] for k, v in sd.items())
+    opts, scheds = model.configure_optimizers()
+    assert len(opts) == len(scheds) == 3
+    nets = model.optimizer_networks()
+    for opt, net in zip(opts, nets):
+        assert [id(p) for grp in opt.param_groups for p in grp["params"]] == [id(p) for p in net.parameters()]
+    assert [grp["lr"] for o in opts for grp in o.param_groups] == [1e-4, 3e-4, 3e-4]
+
+
+def test_sams_options_and_reference_quirks():
+    import sams_helpers as sh
+    from shineon_virtual_tryon_amd.networks.normalization import get_nonspade_norm_layer
+    from shineon_virtual_tryon_amd.networks.layers import HipConv2d
+    from shineon_virtual_tryon_amd.networks.sams.sams_generator import SamsGenerator, choose_spade_class_by_index
+    from shineon_virtual_tryon_amd.networks.sams import AttentiveMultiSpade, MultiSpade, SPADE
+    from shineon_virtual_tryon_amd.options import TrainOptions
+
+    opt = TrainOptions().parse(["--model", "sams", "--dataset", "synthetic", "--name", "t"], interactive=False)
+    # the model's set_defaults(n_frames_total=5) loses against the dataset's explicit `--n_frames_total default=1`, added
+    # later (datasets/n_frames_interface.py:35-38) - in the reference too; batch_size (declared earlier) does become 4
+    assert opt.n_frames_total == 1 and opt.batch_size == 4 and opt.encoder_input == "flow"
+    assert opt.person_inputs == ["agnostic", "densepose", "flow"] and opt.norm_G == "spectralspadesyncbatch3x3"
+    assert (opt.ngf_base, opt.ngf_pow_outer, opt.ngf_pow_inner, opt.num_middle) == (2, 6, 10, 3)
+    assert (opt.gan_mode, opt.lr_D, opt.num_D, opt.n_layers_D, opt.ndf, opt.norm_D) == ("hinge", 3e-4, 2, 4, 64, "spectralinstance")
+    assert (opt.init_type, opt.init_variance) == ("xavier", 0.02)
+    opt = TrainOptions().parse(["--model", "sams", "--dataset", "synthetic", "--name", "t", "--n_frames_total", "5"],
+                               interactive=False)
+    assert opt.n_frames_total == 5 and opt.n_frames_now == 5
+    # attention placement takes positive or negative indices, as strings
+    assert choose_spade_class_by_index(["0"], 0, 3) is AttentiveMultiSpade and choose_spade_class_by_index(["-1"], 2, 3) is AttentiveMultiSpade
+    assert choose_spade_class_by_index(["0"], 1, 3) is MultiSpade
+    with pytest.raises(ValueError):
+        SPADE.parse_config_text("spadegroup3x3")
+    # a norm_D that does not start with "spectral" dies like the reference (unbound subnorm_type)
+    with pytest.raises(UnboundLocalError):
+        get_nonspade_norm_layer(None, "instance")(HipConv2d(4, 4, 4))
+    # the default generator: 64 .. 1024 features, 4 encoder + 3 middle + 4 decoder blocks
+    gen = SamsGenerator(sh.sams_hparams(ngf_pow_outer=6, ngf_pow_inner=10, num_middle=3, n_frames_total=5))
+    assert [type(m).__name__ for m in gen.encode_layers] == ["HipConv2d"] + ["AnySpadeResBlock", "NearestResize"] * 4
+    assert len(gen.middle_layers) == 3 and len(gen.decode_layers) == 9
+    assert gen.encode_layers[0].in_channels == 12 and gen.decode_layers[-1].out_channels == 4
+    assert gen.middle_layers[0].conv_0.weight_orig.shape == (1024, 1024, 3, 3)
+    with pytest.raises(IndexError):
+        SamsGenerator(sh.sams_hparams(n_frames_total=1))(None, None, {})
+
+
+def test_sams_init_weights_visiting_rules():
+    """BaseNetwork.init_weights (base_network.py:42-77): conv weights drawn (through weight_orig when spectrally
+    normalised), ALL conv biases zeroed, affine BatchNorm scale ~ N(1, gain); sub-networks that own an init_weights are
+    drawn a second time, so the stream position after the call is what the reference's would be."""
+    import sams_helpers as sh
+    from shineon_virtual_tryon_amd.networks.discriminator import MultiscaleDiscriminator, NLayerDiscriminator
+
+    hp = sh.sams_hparams(norm_D="spectralbatch")
+    torch.manual_seed(5)
+    d = NLayerDiscriminator(hp, in_channels=15)
+    torch.manual_seed(77)
+    d.init_weights("xavier", 0.02)
+    w = d.model0[0].weight
+    fan = (w.shape[1] + w.shape[0]) * 16
+    assert abs(float(w.std()) - 0.02 * (2.0 / fan) ** 0.5) < 0.1 * 0.02 * (2.0 / fan) ** 0.5
+    assert float(d.model0[0].bias.abs().max()) == 0.0 and float(d.model4[0].bias.abs().max()) == 0.0
+    bn = d.model1[0][1]
+    assert abs(float(bn.weight.mean()) - 1.0) < 0.02 and float(bn.bias.abs().max()) == 0.0
+    wo = d.model1[0][0].weight_orig
+    fan = (wo.shape[1] + wo.shape[0]) * 16
+    assert abs(float(wo.std()) - 0.02 * (2.0 / fan) ** 0.5) < 0.15 * 0.02 * (2.0 / fan) ** 0.5
+    # the multiscale wrapper initialises its children a second time: the values that stay are the second draw
+    torch.manual_seed(5)
+    ms = MultiscaleDiscriminator(hp)
+    torch.manual_seed(77)
+    ms.init_weights("normal", 0.02)
+    first = ms.discriminator_0.model0[0].weight.clone()
+    torch.manual_seed(77)
+    ms.init_weights("normal", 0.02)
+    assert torch.equal(first, ms.discriminator_0.model0[0].weight)      # deterministic given the seed
+    torch.manual_seed(77)
+    ms.discriminator_0.init_weights("normal", 0.02)
+    assert not torch.equal(first, ms.discriminator_0.model0[0].weight)  # a single pass lands on other stream positions
+    with pytest.raises(NotImplementedError):
+        d.init_weights("he_uniform")
+
+
+@pytest.mark.parametrize("tag,kw", [("xavier", dict()), ("normal_batchD", dict(norm_D="spectralbatch", init_type="normal")),
+                                    ("kaiming_attn", dict(init_type="kaiming", attention_middle_indices=["0"],
+                                                          norm_G="spadeinstance3x3"))])
+def test_sams_init_weights_matches_the_reference_stream(tag, kw):
+    """Same seed, same call: every parameter of the generator and both discriminators after init_weights equals what the
+    reference's BaseNetwork.init_weights produced (tests/golden/sams_init.npz), and the global generator ends at the same
+    position - so the visiting order, the double pass over sub-discriminators and the weight_orig alias are all the
+    reference's."""
+    import sams_helpers as sh
+    from shineon_virtual_tryon_amd.networks.discriminator import MultiscaleDiscriminator, NLayerDiscriminator
+    from shineon_virtual_tryon_amd.networks.sams.sams_generator import SamsGenerator
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sams_init.npz"))
+    hp = sh.sams_hparams(**kw)
+    torch.manual_seed(99)
+    nets = {"G": SamsGenerator(hp), "Dm": MultiscaleDiscriminator(hp), "Dt": NLayerDiscriminator(hp, in_channels=15)}
+    torch.manual_seed(1234)
+    for name, net in nets.items():
+        net.init_weights(hp.init_type, hp.init_variance)
+        for k, p in net.named_parameters():
+            cs = helpers.checksums(p.detach().contiguous())  # logical (O, I, R, S) order, like the reference's tensor
+            assert np.array_equal(cs, g[f"{tag}:{name}.{k}"]), (tag, name, k, cs, g[f"{tag}:{name}.{k}"])
+        k0, p0 = next(iter(net.named_parameters()))
+        assert np.array_equal(p0.detach().contiguous().numpy(), g[f"{tag}:full:{name}.{k0}"])
+    assert np.array_equal(torch.rand(4).numpy(), g[f"{tag}:next_random"])

@@ -383,22 +383,3 @@ def test_sams_eval_mode_uses_running_statistics_and_leaves_buffers_alone():
     for k, v in model.state_dict().items():
         if k in before:
             assert torch.equal(v, before[k]), k
-
-
-def test_sams_registry_and_options():
-    from shineon_virtual_tryon_amd import registry
-    from shineon_virtual_tryon_amd.options import TrainOptions
-    from shineon_virtual_tryon_amd.sams_model import SamsModel
-
-    assert registry.find_model_using_name("sams") is SamsModel
-    opt = TrainOptions().parse(["--model", "sams", "--dataset", "synthetic", "--name", "t"], interactive=False)
-    # the model's set_defaults(n_frames_total=5) loses against the dataset's explicit `--n_frames_total default=1`, added
-    # later (datasets/n_frames_interface.py:35-38) - in the reference too; batch_size (declared earlier) does become 4
-    assert opt.n_frames_total == 1 and opt.batch_size == 4 and opt.encoder_input == "flow"
-    opt = TrainOptions().parse(["--model", "sams", "--dataset", "synthetic", "--name", "t", "--n_frames_total", "5"],
-                               interactive=False)
-    assert opt.n_frames_total == 5 and opt.n_frames_now == 5
-    assert opt.person_inputs == ["agnostic", "densepose", "flow"] and opt.norm_G == "spectralspadesyncbatch3x3"
-    assert (opt.ngf_base, opt.ngf_pow_outer, opt.ngf_pow_inner, opt.num_middle) == (2, 6, 10, 3)
-    assert (opt.gan_mode, opt.lr_D, opt.num_D, opt.n_layers_D, opt.ndf, opt.norm_D) == ("hinge", 3e-4, 2, 4, 64, "spectralinstance")
-    assert opt.init_type == "xavier" and opt.init_variance == 0.02
