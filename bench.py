@@ -41,7 +41,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
-GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None}  # c5: taken from the MFMA launches' own 2MNK sum
+GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": None}  # None: the MFMA launches' own 2MNK sum
 WORKLOADS = {
     "c4": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then UnetMaskModel "
           "(self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, 256x192",
@@ -50,7 +50,148 @@ WORKLOADS = {
     "c5": "BASELINE config 5: UnetMaskModel with n_frames_total=5, flow_warp (ngf=167, 50 in / 25 out channels, 154 M parameters, "
           "Resample2d chain, flow-mask penalty), bs=2 sequences of 5 frames per GPU, fwd+bwd+Adam, 256x192; flow fields synthetic "
           "(FlowNet2 stays upstream)",
+    "sams": "SURVEY 8f-4: SamsModel (Self-Attentive Multi-SPADE GAN) with the reference's default networks (generator 64..1024 "
+            "features, 4 encoder + 3 middle + 4 decoder SPADE blocks, spectral norm; 2-scale + temporal PatchGAN discriminators, "
+            "hinge loss), n_frames_total=5, flow_warp, 256x192; one step = the three optimizers in Lightning's order "
+            "(generator: 5 generator passes fwd+bwd + both discriminators + L1 + VGG19; multiscale D: 5 more generator passes "
+            "under no_grad + D fwd+bwd; temporal D fwd+bwd), each with its Adam update",
 }
+
+
+def sams_hparams(**kw):
+    base = dict(n_frames_total=5, n_frames_now=None, person_inputs=["agnostic", "densepose", "flow"], cloth_inputs=["cloth"],
+                encoder_input="flow", flow_warp=True, activation="relu", fine_height=256, fine_width=192, is_train=True,
+                norm_G="spectralspadesyncbatch3x3", ngf_base=2, ngf_pow_outer=6, ngf_pow_inner=10, ngf_pow_step=1, num_middle=3,
+                attention_middle_indices=[], attention_decoder_indices=[], init_type="xavier", init_variance=0.02,
+                netD_subarch="n_layer", num_D=2, n_layers_D=4, ndf=64, norm_D="spectralinstance", gan_mode="hinge", lr=1e-4,
+                lr_D=3e-4, no_ganFeat_loss=False, wt_l1=1.0, wt_vgg=1.0, wt_multiscale=1.0, wt_temporal=1.0,
+                display_count=10 ** 9, keep_epochs=5, decay_epochs=5, allow_random_vgg=True)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def sams_cpu_baseline(batch_size):
+    """The SAMS oracle on this host's cores, on a BOUNDED sample of the step: the same networks at 256x192 with
+    n_frames_total=2 (one previous frame instead of four: 2/5 of the generator passes, everything else per step unchanged),
+    one untimed + one timed three-optimizer step."""
+    from oracle import sams_oracle as so
+    from oracle.procedural import procedural_state_dict, shapes_of
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+
+    torch.set_num_threads(usable_cores())
+    hp = sams_hparams(n_frames_total=2)
+    sd = procedural_state_dict(shapes_of(SamsModel(hp).state_dict()))
+    batch = synthetic_batch(batch_size, "cpu", n_frames=2)
+    groups = so.optimizer_groups(sd)
+    oracle = so.SamsOracle(sd, hp)
+    nets = ("generator", "multiscale_discriminator", "temporal_discriminator")
+    for net in nets:
+        for k in groups[net]:
+            sd[k].requires_grad_(True)
+    opts = [torch.optim.Adam([sd[k] for k in groups[net]], lr) for net, lr in zip(nets, (hp.lr, hp.lr_D, hp.lr_D))]
+
+    def step():
+        for idx, net in enumerate(nets):
+            for k, v in sd.items():
+                if v.is_floating_point():
+                    v.requires_grad_(k in groups[net])
+            loss, _ = (oracle.generator_step, oracle.multiscale_discriminator_step, oracle.temporal_discriminator_step)[idx](batch)
+            opts[idx].zero_grad()
+            loss.sum().backward()
+            opts[idx].step()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return {"value": batch_size * 2 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+            "sample": f"1 warm-up + 1 timed three-optimizer SamsModel step of the oracle at 256x192, bs={batch_size}, reduced to "
+                      f"n_frames_total=2 (2 instead of 5 generator passes per generation; bounded CPU time), PyTorch CPU fp32: "
+                      f"{dt:.1f} s/step"}
+
+
+def run_sams(args, trainer, L):
+    """--config sams: SamsModel's three-optimizer step through trainer.MultiOptimizerStep (eager launches)."""
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+    from shineon_virtual_tryon_amd.trainer import MultiOptimizerStep
+
+    rank, world, dev = trainer.rank, trainer.world, trainer.device
+    hp = sams_hparams()
+    nfr = hp.n_frames_total
+    torch.manual_seed(420)
+    model = SamsModel(hp).to(dev).train()
+    model.global_step = 1
+    batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch, n_frames=nfr)
+    opts, _ = model.configure_optimizers()
+    for o in opts:
+        broadcast_parameters(model, optimizer=o)
+    engine = MultiOptimizerStep(model, opts)
+    nparams = [sum(p.numel() for p in net.parameters()) for net in model.optimizer_networks()]
+    log(f"SamsModel: generator {nparams[0] / 1e6:.1f} M, multiscale D {nparams[1] / 1e6:.1f} M, temporal D {nparams[2] / 1e6:.1f} M "
+        f"parameters; bs={args.batch} x {nfr} frames")
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
+        engine(batch, i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - t_w):.1f} ms, peak HBM {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    L.so_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        engine(batch, i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    L.so_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = (ctypes.c_float * 32)()
+    fl = (ctypes.c_float * 32)()
+    cnt = (ctypes.c_int * 32)()
+    L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
+    if rank != 0:
+        return
+    kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / args.steps,
+                              "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(32) if cnt[k] > 0}
+    dom = max(range(32), key=lambda k: ms[k])
+    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    step_ms = 1e3 * elapsed / args.steps
+    gf_step = sum(fl) / args.steps / 1e9
+    mfma_ms = sum(ms) / args.steps
+    out = {
+        "metric": "SAMS-GAN video frames/sec (three-optimizer step, fwd+bwd+Adam) at 256x192, n_frames=5",
+        "value": world * args.batch * nfr * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": WORKLOADS["sams"], "config": "sams", "launch": "eager (hip events bracket every MFMA launch)",
+                   "batch_per_gpu": args.batch, "global_batch": world * args.batch, "frames_per_sample": nfr,
+                   "parallelism": f"dp{world}", "step_api": "shineon_virtual_tryon_amd.trainer.MultiOptimizerStep",
+                   "parameters_M": [round(n / 1e6, 2) for n in nparams],
+                   "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+        "roofline": {
+            "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "timing": "hip events, eager launches in the timed region", "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+            "step": {"algorithmic_gflop_per_step": gf_step, "achieved": gf_step / step_ms,
+                     "frac": gf_step / step_ms / PEAK_FP32_MFMA_TFLOPS,
+                     "note": "2MNK of every MFMA launch of the step / measured step time / fp32-MFMA peak"},
+            "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / step_ms,
+            "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
+        },
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = sams_cpu_baseline(args.batch)
+    print(json.dumps(out), flush=True)
+
 
 
 def hparams(**kw):
@@ -205,7 +346,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (BASELINE: 4)")
-    ap.add_argument("--config", choices=("c4", "c2", "c3", "c5"), default="c4",
+    ap.add_argument("--config", choices=("c4", "c2", "c3", "c5", "sams"), default="c4",
                     help="c4: chained warp->try-on step (headline); c2: WarpModel alone; c3: UnetMaskModel alone; "
                          "c5: 5-frame flow_warp UnetMaskModel, bs=2 sequences (frames/s counts bs x 5 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,6 +379,16 @@ def main():
         so_ops.VGG_SPLIT_BF16 = True
     torch.manual_seed(420)
     cfg = args.config
+    if cfg == "sams":
+        if args.batch == 4 and "--batch" not in sys.argv:
+            args.batch = 1  # five generator passes keep ~60 GB of activations per sample alive for the backward pass
+        if "--steps" not in sys.argv:
+            args.steps, args.warmup = 3, 1
+        run_sams(args, trainer, L)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if cfg == "c5" and args.batch == 4:
         args.batch = 2   # BASELINE config 5: bs = 2 per GPU
     nfr = 5 if cfg == "c5" else 1

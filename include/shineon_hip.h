@@ -350,6 +350,9 @@ int so_resize_nearest_fwd(const float* x, int ldx, float* y, int ldy, int Nb, in
 int so_resize_nearest_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, int Hi, int Wi, int Ho, int Wo, int C,
                           float scale_h, float scale_w, void* stream);
 
+/* y = a + b: the residual connection of AnySpadeResBlock (models/networks/sams/spade.py:171) */
+int so_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, long long rows, int C, void* stream);
+
 /* SPADE modulation (models/networks/sams/spade.py:89) fused with the activation AnySpadeResBlock applies to it
  * (spade.py:168-169): y = act(nrm * (1 + gamma) + beta).  gamma / beta: [rows][C] each (two halves of one conv output
  * are fine: same ld, pointers C apart).  _bwd recomputes the pre-activation and writes dn, dgamma, dbeta. */

@@ -82,6 +82,20 @@ __global__ __launch_bounds__(256) void resize_nearest_bwd_k(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ residual add
+template <int VEC>
+__global__ __launch_bounds__(256) void add_k(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                             float* __restrict__ y, int ldy, unsigned rows, unsigned C) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const unsigned CQ = C / VEC;
+  const unsigned total = rows * CQ;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / CQ, c0 = (idx - row * CQ) * VEC;
+    *reinterpret_cast<vec_t*>(y + (size_t)row * ldy + c0) = *reinterpret_cast<const vec_t*>(a + (size_t)row * lda + c0) +
+                                                            *reinterpret_cast<const vec_t*>(b + (size_t)row * ldb + c0);
+  }
+}
+
 // ------------------------------------------------------------------ SPADE modulation
 template <int VEC>
 __global__ __launch_bounds__(256) void spade_fwd_k(const float* __restrict__ nrm, int ldn, const float* __restrict__ gamma,
@@ -186,15 +200,35 @@ __device__ __forceinline__ unsigned v_logical(unsigned j, unsigned I, unsigned R
   return i * RS + rs;
 }
 
-// t[j] = sum_o W[o][j] * u[o]  (physical column order);  part[block] = sum over the block's columns of t^2
+// tp[oc][j] = sum over the rows of chunk oc of W[o][j] * u[o]  (physical column order).  With one chunk (gridDim.y == 1)
+// tp is t itself and part[block] = sum over the block's columns of t^2; otherwise sn_tsum_k finishes the job.
 __global__ __launch_bounds__(256) void sn_wtu_k(const float* __restrict__ w, const float* __restrict__ u, unsigned O,
-                                                unsigned K, float* __restrict__ t, float* __restrict__ part) {
+                                                unsigned K, unsigned rows_per_chunk, float* __restrict__ tp,
+                                                float* __restrict__ part) {
+  __shared__ float red[4];
+  const unsigned j = blockIdx.x * 256u + threadIdx.x;
+  const unsigned o0 = blockIdx.y * rows_per_chunk;
+  const unsigned o1 = min(o0 + rows_per_chunk, O);
+  float acc = 0.f;
+  if (j < K) {
+#pragma unroll 4
+    for (unsigned o = o0; o < o1; ++o) acc += w[(size_t)o * K + j] * u[o];
+    tp[(size_t)blockIdx.y * K + j] = acc;
+  }
+  if (gridDim.y == 1) {
+    const float s = so_block_sum256(j < K ? acc * acc : 0.f, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+  }
+}
+
+// t[j] = sum_oc tp[oc][j] (fixed order: deterministic);  part[block] = sum over the block's columns of t^2
+__global__ __launch_bounds__(256) void sn_tsum_k(const float* __restrict__ tp, unsigned chunks, unsigned K,
+                                                 float* __restrict__ t, float* __restrict__ part) {
   __shared__ float red[4];
   const unsigned j = blockIdx.x * 256u + threadIdx.x;
   float acc = 0.f;
   if (j < K) {
-#pragma unroll 4
-    for (unsigned o = 0; o < O; ++o) acc += w[(size_t)o * K + j] * u[o];
+    for (unsigned c = 0; c < chunks; ++c) acc += tp[(size_t)c * K + j];
     t[j] = acc;
   }
   const float s = so_block_sum256(j < K ? acc * acc : 0.f, red);
@@ -391,6 +425,16 @@ int so_resize_nearest_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb
   return SO_LAUNCH_CHECK();
 }
 
+int so_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, long long rows, int C, void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4(C, lda, ldb, a, b) && (ldy & 3) == 0 && al16(y))
+    hipLaunchKernelGGL(add_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, st, a, lda, b, ldb, y, ldy, (unsigned)rows, (unsigned)C);
+  else
+    hipLaunchKernelGGL(add_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, a, lda, b, ldb, y, ldy, (unsigned)rows, (unsigned)C);
+  return SO_LAUNCH_CHECK();
+}
+
 int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, float* y, int ldy,
                  long long rows, int C, int act, float act_param, void* stream) {
   if (rows <= 0 || C <= 0) return 0;
@@ -437,9 +481,15 @@ int so_avgpool3s2_bwd(const float* dy, int lddy, float* dx, int lddx, int Nb, in
   return SO_LAUNCH_CHECK();
 }
 
+static inline unsigned sn_chunks(int O) {  // row chunks of the W^T u pass: enough blocks to fill the chip on big layers
+  unsigned c = (unsigned)(O + 63) / 64;
+  return c > 16 ? 16 : (c < 1 ? 1 : c);
+}
+
 long long so_spectral_norm_ws_floats(int O, int I, int RS) {
   const long long K = (long long)I * RS;
-  return K + O + 8 + 1024 + (K + 255) / 256;  // t, s, scalars (1 / |t|, sigma), partial sums
+  // t, s, scalars (1 / |t|, sigma), partial sums (also the 1024 of the backward pass), row-chunk partials of W^T u
+  return K + O + 8 + 1024 + (K + 255) / 256 + (long long)sn_chunks(O) * K;
 }
 
 int so_spectral_norm_fwd(const float* w_orig, int O, int I, int RS, float* u, float* v, float* w_out, float* sigma,
@@ -453,7 +503,15 @@ int so_spectral_norm_fwd(const float* w_orig, int O, int I, int RS, float* u, fl
   float* part = scal + 8;
   const unsigned nparts = (K + 255) / 256;
   if (power_iter) {
-    hipLaunchKernelGGL(sn_wtu_k, dim3(nparts), dim3(256), 0, st, w_orig, (const float*)u, (unsigned)O, K, t, part);
+    const unsigned chunks = sn_chunks(O);
+    if (chunks == 1) {
+      hipLaunchKernelGGL(sn_wtu_k, dim3(nparts, 1), dim3(256), 0, st, w_orig, (const float*)u, (unsigned)O, K, (unsigned)O, t, part);
+    } else {
+      float* tp = part + 1024 + nparts;
+      const unsigned rpc = ((unsigned)O + chunks - 1) / chunks;
+      hipLaunchKernelGGL(sn_wtu_k, dim3(nparts, chunks), dim3(256), 0, st, w_orig, (const float*)u, (unsigned)O, K, rpc, tp, part);
+      hipLaunchKernelGGL(sn_tsum_k, dim3(nparts), dim3(256), 0, st, (const float*)tp, chunks, K, t, part);
+    }
     hipLaunchKernelGGL(sn_wv_k, dim3((O + 3) / 4), dim3(256), 0, st, w_orig, (const float*)t, (const float*)part, nparts,
                        (unsigned)O, K, (unsigned)I, (unsigned)RS, eps, 1, s, scal);
   } else {

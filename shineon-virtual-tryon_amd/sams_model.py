@@ -102,6 +102,13 @@ class SamsModel(BaseModel):
     def batch_keys(self):
         return sorted({"image", self.hparams.encoder_input, *self.inputs})
 
+    def require_pretrained_vgg(self):
+        """Called by Trainer.fit before training: the reference trains against ImageNet VGG19 features
+        (models/networks/vgg.py:9); random ones only when explicitly allowed (synthetic benchmarks, tests)."""
+        if not self.criterion_VGG.vgg.pretrained_loaded and not getattr(self.hparams, "allow_random_vgg", False):
+            raise RuntimeError("SamsModel: no pretrained VGG19 weights for the perceptual loss (torchvision is not installed / "
+                               "offline). Pass --vgg_weights <vgg19 state_dict or checkpoint>, or --allow_random_vgg.")
+
     # ---- frames ------------------------------------------------------------------------------------
     @property
     def all_gen_frames(self):

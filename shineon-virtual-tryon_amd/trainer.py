@@ -422,7 +422,9 @@ class MultiOptimizerStep:
         return results
 
     def flush(self):
-        pass
+        """Nothing is left in flight by an eager step; what a checkpoint / validation must not see is the requires_grad
+        pattern of the last optimizer, so that is put back."""
+        self.restore_requires_grad()
 
 
 class DeviceBatches:
@@ -528,8 +530,8 @@ class Trainer:
             return
         ckpt = torch.load(self.resume, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ckpt["state_dict"], strict=True)
-        vgg = getattr(getattr(self.model, "criterionVGG", None), "vgg", None)
-        if vgg is not None and any(k.startswith("criterionVGG.") for k in ckpt["state_dict"]):
+        vgg = getattr(_vgg_criterion(self.model), "vgg", None)
+        if vgg is not None and any(k.startswith(("criterionVGG.", "criterion_VGG.")) for k in ckpt["state_dict"]):
             # the VGG weights now are the checkpoint's: pretrained unless the checkpoint says it was trained on random ones
             # (reference checkpoints carry no flag and always hold ImageNet weights, models/networks/vgg.py:9)
             vgg.pretrained_loaded = bool(ckpt.get("vgg_pretrained", True))
@@ -692,6 +694,12 @@ class Trainer:
         return outs
 
 
-def _vgg_flag(model):
+def _vgg_criterion(model):
+    """The perceptual-loss module: `criterionVGG` in UnetMaskModel, `criterion_VGG` in SamsModel (the reference's names)."""
     crit = getattr(model, "criterionVGG", None)
+    return crit if crit is not None else getattr(model, "criterion_VGG", None)
+
+
+def _vgg_flag(model):
+    crit = _vgg_criterion(model)
     return bool(getattr(getattr(crit, "vgg", None), "pretrained_loaded", False)) if crit is not None else None
