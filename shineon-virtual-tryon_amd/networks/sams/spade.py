@@ -7,6 +7,7 @@ single pass that also applies the residual block's activation when one follows.
 """
 import re
 
+import torch
 from torch import nn
 
 from ... import ops, ops_sams
@@ -18,6 +19,24 @@ from ..sync_batchnorm import SynchronizedBatchNorm2d
 # LeakyReLU(0.2) (spade.py:182-192).
 _MLP_ACT = {"relu": ("relu", 0.0), "gelu": ("gelu", 0.0), "swish": ("swish", 0.0), "sine": ("sine", 0.0)}
 _BLOCK_ACT = {"relu": ("leaky", 0.2), "gelu": ("gelu", 0.0), "swish": ("swish", 0.0), "sine": ("sine", 0.0)}
+
+
+class stacked_weight_cache:
+    """Context manager: inside it every SPADE stacks its mlp_gamma / mlp_beta parameters ONCE and reuses the result.
+    SamsModel.generate_n_frames runs the generator once per frame with the same weights, so the 84 SPADEs of the default
+    generator stack 5x less often; under autograd the passes share one node, whose gradient is split back into the two
+    parameters once.  Nothing is cached outside the context (an optimizer step in between would make it stale)."""
+
+    active = None
+
+    def __enter__(self):
+        self.prev = stacked_weight_cache.active
+        stacked_weight_cache.active = {}
+        return self
+
+    def __exit__(self, *exc):
+        stacked_weight_cache.active = self.prev
+        return False
 
 
 def _lookup(table, name):
@@ -58,7 +77,14 @@ class SPADE(nn.Module):
         actv = self.mlp_shared[0](seg)
         if self.mlp_act[0] != "relu":
             actv = ops.activation(actv, *self.mlp_act)
-        w2, b2 = ops_sams.stack_conv_params(self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
+        cache = stacked_weight_cache.active
+        key = (id(self), torch.is_grad_enabled())
+        if cache is not None and key in cache:
+            w2, b2 = cache[key]
+        else:
+            w2, b2 = ops_sams.stack_conv_params(self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
+            if cache is not None:
+                cache[key] = (w2, b2)
         gamma_beta = ops.conv2d(actv, w2, b2, 1, self.mlp_gamma.padding)
         kind, param = then_act if then_act is not None else ("none", 0.0)
         return ops_sams.spade_modulate(normalized, gamma_beta, kind, param)

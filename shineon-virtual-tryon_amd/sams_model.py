@@ -24,6 +24,7 @@ from .base_model import BaseModel
 from .networks.discriminator import MultiscaleDiscriminator, NLayerDiscriminator
 from .networks.loss import GANLoss, VGGLoss
 from .networks.sams.sams_generator import SamsGenerator
+from .networks.sams.spade import stacked_weight_cache
 from .optim import HipAdam
 from .pl_compat import EvalResult, TrainResult
 from .unet_mask_model import Resample2d
@@ -163,17 +164,18 @@ class SamsModel(BaseModel):
         zero = ops.fill_(ops.nhwc_empty(b, h, w, tc.RGB_CHANNELS, image.device), 0.0)
         frames = [None] * n
         fake = maps_now = None
-        for f in range(n - self.n_frames_now, n):
-            maps_now = {k: ops.to_rows(batch[k][:, f]) for k in self.inputs}
-            prev_frames, prev_maps = self._previous_inputs(batch, f, frames, zero)
-            out = self.generator(prev_frames, prev_maps, maps_now)
-            if hp.flow_warp:
-                last = frames[f - 1] if f > 0 and frames[f - 1] is not None else zero
-                warped = self.resample(last, batch["flow"][:, f].contiguous())
-                fake = ops.blend(warped, out[:, :3], out[:, 3:])  # (1 - m) * warped + m * rgb
-            else:
-                fake = out[:, :3] if out.shape[1] > 3 else out
-            frames[f] = fake
+        with stacked_weight_cache():  # the weights do not change between the passes of one generation
+            for f in range(n - self.n_frames_now, n):
+                maps_now = {k: ops.to_rows(batch[k][:, f]) for k in self.inputs}
+                prev_frames, prev_maps = self._previous_inputs(batch, f, frames, zero)
+                out = self.generator(prev_frames, prev_maps, maps_now)
+                if hp.flow_warp:
+                    last = frames[f - 1] if f > 0 and frames[f - 1] is not None else zero
+                    warped = self.resample(last, batch["flow"][:, f].contiguous())
+                    fake = ops.blend(warped, out[:, :3], out[:, 3:])  # (1 - m) * warped + m * rgb
+                else:
+                    fake = out[:, :3] if out.shape[1] > 3 else out
+                frames[f] = fake
         return fake, maps_now, frames
 
     def mask_unused_frames(self, tensor):
