@@ -110,6 +110,71 @@ def sams_cpu_baseline(batch_size):
                       f"{dt:.1f} s/step"}
 
 
+def sams_hbm_table(dev, batch_size):
+    """GB/s of the SAMS-only bandwidth-bound kernels (csrc/sams.hip) at the step's own tensor sizes: stand-alone launches,
+    20 repetitions, HIP events on the launch stream, algorithmic bytes per DESIGN.md 3.6, against the 8 TB/s HBM peak."""
+    from shineon_virtual_tryon_amd import ops_sams
+
+    L = pkg.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    f = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+    n = batch_size
+    rows, c = n * 256 * 192, 64
+    x, gb, y, dy = f(rows, c), f(rows, 2 * c), f(rows, c), f(rows, c)
+    dn, dgb = torch.empty_like(x), torch.empty_like(gb)
+    cases = {}
+    cases["spade modulation fwd + LeakyReLU (256x192, C=64; 16 B/elem)"] = (
+        lambda: L.so_spade_fwd(x.data_ptr(), c, gb.data_ptr(), 2 * c, gb.data_ptr() + 4 * c, 2 * c, y.data_ptr(), c, rows, c, 2, 0.2, st),
+        rows * c * 16)
+    cases["spade modulation bwd (256x192, C=64; 28 B/elem)"] = (
+        lambda: L.so_spade_bwd(x.data_ptr(), c, gb.data_ptr(), 2 * c, gb.data_ptr() + 4 * c, 2 * c, dy.data_ptr(), c, dn.data_ptr(), c,
+                               dgb.data_ptr(), 2 * c, dgb.data_ptr() + 4 * c, 2 * c, rows, c, 2, 0.2, st), rows * c * 28)
+    cases["residual add (256x192, C=64; 12 B/elem)"] = (
+        lambda: L.so_add(x.data_ptr(), c, dy.data_ptr(), c, y.data_ptr(), c, rows, c, st), rows * c * 12)
+    lab = f(n * 256 * 192, 4)
+    lab2 = torch.empty(n * 128 * 96, 4, device=dev)
+    cases["nearest resize of a label map (256x192 -> 128x96, C=4)"] = (
+        lambda: L.so_resize_nearest_fwd(lab.data_ptr(), 4, lab2.data_ptr(), 4, n, 256, 192, 128, 96, 4, 2.0, 2.0, st), lab2.numel() * 8)
+    xa = f(n * 128 * 96, 128)
+    xb = torch.empty(n * 256 * 192, 128, device=dev)
+    cases["nearest x2 of an activation (128x96 -> 256x192, C=128)"] = (
+        lambda: L.so_resize_nearest_fwd(xa.data_ptr(), 128, xb.data_ptr(), 128, n, 128, 96, 256, 192, 128, 0.5, 0.5, st),
+        (xa.numel() + xb.numel()) * 4)
+    din = f(2 * n * 256 * 192, 15)
+    dout = torch.empty(2 * n * 128 * 96, 15, device=dev)
+    cases["avg_pool 3x3 s2 of the discriminator input (2B x 256x192, C=15)"] = (
+        lambda: L.so_avgpool3s2_fwd(din.data_ptr(), 15, dout.data_ptr(), 15, 2 * n, 256, 192, 15, st), (din.numel() + dout.numel()) * 4)
+    o, i, rs = 1024, 1024, 9
+    w = f(o, rs, i) * 0.02
+    wo = torch.empty_like(w)
+    u = torch.nn.functional.normalize(f(o), dim=0)
+    v = torch.nn.functional.normalize(f(i * rs), dim=0)
+    sig = torch.empty(1, device=dev)
+    ws = torch.empty(L.so_spectral_norm_ws_floats(o, i, rs), device=dev)
+    cases["spectral norm fwd, 1024x1024x3x3 (3 reads + 1 write of W)"] = (
+        lambda: L.so_spectral_norm_fwd(w.data_ptr(), o, i, rs, u.data_ptr(), v.data_ptr(), wo.data_ptr(), sig.data_ptr(), 1, 1e-12,
+                                       ws.data_ptr(), st), w.numel() * 16)
+    gw = f(o, rs, i)
+    dw = torch.empty_like(w)
+    cases["spectral norm bwd, 1024x1024x3x3 (3 reads + 1 write of W)"] = (
+        lambda: L.so_spectral_norm_bwd(gw.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr(), o, i, rs, dw.data_ptr(), 0,
+                                       ws.data_ptr(), st), w.numel() * 16)
+    out = {}
+    for name, (fn, nbytes) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out[name] = {"bytes": nbytes, "avg_us": round(us, 2), "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / PEAK_HBM_GBS, 3)}
+    return out
+
+
 def run_sams(args, trainer, L):
     """--config sams: SamsModel's three-optimizer step through trainer.MultiOptimizerStep (eager launches)."""
     from shineon_virtual_tryon_amd.sams_model import SamsModel
@@ -188,6 +253,10 @@ def run_sams(args, trainer, L):
         },
         "kernels": kernels,
     }
+    if not args.no_hbm_table:
+        del model, engine, opts, batch
+        torch.cuda.empty_cache()
+        out["roofline"]["hbm"] = {"peak_GB/s": PEAK_HBM_GBS, "kernels": sams_hbm_table(dev, args.batch)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = sams_cpu_baseline(args.batch)
     print(json.dumps(out), flush=True)

@@ -259,7 +259,16 @@ __global__ __launch_bounds__(256) void sn_wv_k(const float* __restrict__ w, cons
   float acc = 0.f;
   const float* wr = w + (size_t)o * K;
   if (power_iter) {
-    for (unsigned j = lane; j < K; j += 64u) acc += wr[j] * t[j];
+    if ((K & 3u) == 0 && ((((uintptr_t)w) | ((uintptr_t)t)) & 15) == 0) {  // 16-byte loads: rows are K floats apart, K % 4 == 0
+      const f32x4* w4 = reinterpret_cast<const f32x4*>(wr);
+      const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+      for (unsigned j = lane; j < K / 4; j += 64u) {
+        const f32x4 a = w4[j], b = t4[j];
+        acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+      }
+    } else {
+      for (unsigned j = lane; j < K; j += 64u) acc += wr[j] * t[j];
+    }
   } else {
     for (unsigned j = lane; j < K; j += 64u) acc += wr[j] * t[v_logical(j, I, RS)];
   }
@@ -291,8 +300,18 @@ __global__ __launch_bounds__(256) void sn_scale_k(const float* __restrict__ w, c
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) sigma_out[0] = sigma;
   const size_t total = (size_t)O * K;
-  for (size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256u)
-    w_out[idx] = w[idx] / sigma;
+  if ((total & 3u) == 0 && ((((uintptr_t)w) | ((uintptr_t)w_out)) & 15) == 0) {
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    f32x4* o4 = reinterpret_cast<f32x4*>(w_out);
+    for (size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; idx < total / 4; idx += (size_t)gridDim.x * 256u) {
+      const f32x4 a = w4[idx];
+      const f32x4 r = {a[0] / sigma, a[1] / sigma, a[2] / sigma, a[3] / sigma};
+      o4[idx] = r;
+    }
+  } else {
+    for (size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256u)
+      w_out[idx] = w[idx] / sigma;
+  }
   if (power_iter) {
     const float inv_t = scal[0];
     for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < K; j += gridDim.x * 256u) v[v_logical(j, I, RS)] = t[j] * inv_t;
