@@ -66,7 +66,7 @@ def kink_shift(delta_rel):
         F.relu, F.leaky_relu = relu, leaky
 
 
-def kink_spread(sd, hp, batch, exact_steps, delta_rel=3e-6):
+def kink_spread(sd, hp, batch, exact_steps, delta_rel=1e-5):
     """Per step: {key: max |gradient(kink at +-delta) - gradient(kink at 0)|} from two more fp64 oracle runs."""
     spread = [dict() for _ in exact_steps]
     for sign in (+1.0, -1.0):

@@ -151,7 +151,7 @@ def _compare_grads(got, ref32, ref64, what, kink=None):
     analytically-zero gradients (fp64 says 0) stay at the oracle's own noise level — plus a conditioning term: the fp32
     oracle's own distance from the fp64 one (`own`) measures how much THIS tensor moves under rounding.  It is ~1e-6 * max
     for almost every tensor; 5 * own is granted (10 * own for scalars, whose cancellation makes them the worst conditioned).
-    kink: {key: spread} from sams_helpers.kink_spread — how far the fp64 gradient moves when a pre-activation within 3e-6
+    kink: {key: spread} from sams_helpers.kink_spread — how far the fp64 gradient moves when a pre-activation within 1e-5
     of a ReLU / LeakyReLU kink takes the other side (0 unless such an element exists; one pixel of these 64 x 48 frames
     then moves a gradient by up to 10 %, in any fp32 implementation)."""
     assert set(got) == set(ref32), (what, set(got) ^ set(ref32))
