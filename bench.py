@@ -122,13 +122,14 @@ def sams_hbm_table(dev, batch_size):
     rows, c = n * 256 * 192, 64
     x, gb, y, dy = f(rows, c), f(rows, 2 * c), f(rows, c), f(rows, c)
     dn, dgb = torch.empty_like(x), torch.empty_like(gb)
+    part = torch.empty(L.so_spade_bwd_colsum_blocks(rows, c), 2 * c, device=dev)  # per-block column sums (bias gradient)
     cases = {}
     cases["spade modulation fwd + LeakyReLU (256x192, C=64; 16 B/elem)"] = (
         lambda: L.so_spade_fwd(x.data_ptr(), c, gb.data_ptr(), 2 * c, gb.data_ptr() + 4 * c, 2 * c, y.data_ptr(), c, rows, c, 2, 0.2, st),
         rows * c * 16)
-    cases["spade modulation bwd (256x192, C=64; 28 B/elem)"] = (
+    cases["spade modulation bwd + bias-gradient partials (256x192, C=64; 28 B/elem)"] = (
         lambda: L.so_spade_bwd(x.data_ptr(), c, gb.data_ptr(), 2 * c, gb.data_ptr() + 4 * c, 2 * c, dy.data_ptr(), c, dn.data_ptr(), c,
-                               dgb.data_ptr(), 2 * c, dgb.data_ptr() + 4 * c, 2 * c, rows, c, 2, 0.2, st), rows * c * 28)
+                               dgb.data_ptr(), 2 * c, dgb.data_ptr() + 4 * c, 2 * c, rows, c, 2, 0.2, part.data_ptr(), st), rows * c * 28)
     cases["residual add (256x192, C=64; 12 B/elem)"] = (
         lambda: L.so_add(x.data_ptr(), c, dy.data_ptr(), c, y.data_ptr(), c, rows, c, st), rows * c * 12)
     lab = f(n * 256 * 192, 4)

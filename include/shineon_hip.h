@@ -360,7 +360,10 @@ int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const f
                  long long rows, int C, int act, float act_param, void* stream);
 int so_spade_bwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, const float* dy, int lddy,
                  float* dn, int lddn, float* dgamma, int lddg, float* dbeta, int lddb, long long rows, int C, int act,
-                 float act_param, void* stream);
+                 float act_param, float* colsum_part, void* stream);
+/* colsum_part (optional): [so_spade_bwd_colsum_blocks(rows, C)][2C] per-block column sums of dgamma | dbeta - summed over
+ * the blocks they are the bias gradient of the convolution that produced gamma | beta.  0 blocks: C not eligible. */
+int so_spade_bwd_colsum_blocks(long long rows, int C);
 
 /* F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False) between the scales of the multiscale discriminator
  * (models/networks/discriminator.py:51-54): Ho = (H - 1) / 2 + 1. */

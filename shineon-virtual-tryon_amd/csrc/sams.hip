@@ -118,15 +118,21 @@ __global__ __launch_bounds__(256) void spade_fwd_k(const float* __restrict__ nrm
 }
 
 // g = dy * act'(pre);  dn = g * (1 + gamma);  dgamma = g * n;  dbeta = g      (pre recomputed from n, gamma, beta)
-template <int VEC>
+// COLSUM (VEC == 4, C / 4 a power of two <= 256): the block also leaves the column sums of its dgamma | dbeta rows in
+// part[blockIdx][2C] - the bias gradient of the convolution that produced gamma | beta, without a second pass over them.
+// Every thread keeps one channel quad for the whole grid-stride loop (256 and the stride are multiples of C / 4).
+template <int VEC, bool COLSUM>
 __global__ __launch_bounds__(256) void spade_bwd_k(const float* __restrict__ nrm, int ldn, const float* __restrict__ gamma,
                                                    int ldg, const float* __restrict__ beta, int ldb,
                                                    const float* __restrict__ dy, int lddy, float* __restrict__ dn, int lddn,
                                                    float* __restrict__ dgamma, int lddg, float* __restrict__ dbeta, int lddb,
-                                                   unsigned rows, unsigned C, int act, float param) {
+                                                   unsigned rows, unsigned C, int act, float param, float* __restrict__ part) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const unsigned CQ = C / VEC;
   const unsigned total = rows * CQ;
+  vec_t sg, sb;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { sg[i] = 0.f; sb[i] = 0.f; }
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / CQ, c0 = (idx - row * CQ) * VEC;
     const vec_t n = *reinterpret_cast<const vec_t*>(nrm + (size_t)row * ldn + c0);
@@ -144,6 +150,24 @@ __global__ __launch_bounds__(256) void spade_bwd_k(const float* __restrict__ nrm
     *reinterpret_cast<vec_t*>(dn + (size_t)row * lddn + c0) = on;
     *reinterpret_cast<vec_t*>(dgamma + (size_t)row * lddg + c0) = og;
     *reinterpret_cast<vec_t*>(dbeta + (size_t)row * lddb + c0) = ob;
+    if constexpr (COLSUM) { sg += og; sb += ob; }
+  }
+  if constexpr (COLSUM) {
+    __shared__ float red[256][2 * VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { red[threadIdx.x][i] = sg[i]; red[threadIdx.x][VEC + i] = sb[i]; }
+    __syncthreads();
+    if (threadIdx.x < CQ) {  // fixed order over the 256 / CQ threads that share this channel quad: deterministic
+      float acc[2 * VEC];
+#pragma unroll
+      for (int i = 0; i < 2 * VEC; ++i) acc[i] = 0.f;
+      for (unsigned t = threadIdx.x; t < 256u; t += CQ)
+#pragma unroll
+        for (int i = 0; i < 2 * VEC; ++i) acc[i] += red[t][i];
+      float* out = part + (size_t)blockIdx.x * 2 * C + threadIdx.x * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) { out[i] = acc[i]; out[C + i] = acc[VEC + i]; }
+    }
   }
 }
 
@@ -467,18 +491,33 @@ int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const f
   return SO_LAUNCH_CHECK();
 }
 
+static inline bool spade_colsum_ok(int C) { return (C & 3) == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
+
+int so_spade_bwd_colsum_blocks(long long rows, int C) {
+  if (!spade_colsum_ok(C)) return 0;
+  int b = grid_for(rows * C / 4);
+  return b > 1024 ? 1024 : b;
+}
+
 int so_spade_bwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, const float* dy, int lddy,
                  float* dn, int lddn, float* dgamma, int lddg, float* dbeta, int lddb, long long rows, int C, int act,
-                 float act_param, void* stream) {
+                 float act_param, float* colsum_part, void* stream) {
   if (rows <= 0 || C <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (vec4(C, ldn, lddy, nrm, dy) && vec4(C, ldg, ldb, gamma, beta) && vec4(C, lddn, lddg, dn, dgamma) &&
-      vec4(C, lddb, lddb, dbeta, dbeta))
-    hipLaunchKernelGGL(spade_bwd_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy,
-                       lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param);
-  else
-    hipLaunchKernelGGL(spade_bwd_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy, lddy,
-                       dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param);
+  const bool v4 = vec4(C, ldn, lddy, nrm, dy) && vec4(C, ldg, ldb, gamma, beta) && vec4(C, lddn, lddg, dn, dgamma) &&
+                  vec4(C, lddb, lddb, dbeta, dbeta);
+  if (colsum_part) {
+    if (!v4 || !spade_colsum_ok(C)) return SO_ERR_ALIGN;
+    hipLaunchKernelGGL((spade_bwd_k<4, true>), dim3(so_spade_bwd_colsum_blocks(rows, C)), dim3(256), 0, st, nrm, ldn, gamma, ldg,
+                       beta, ldb, dy, lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param,
+                       colsum_part);
+  } else if (v4) {
+    hipLaunchKernelGGL((spade_bwd_k<4, false>), dim3(grid_for(rows * C / 4)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy,
+                       lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr);
+  } else {
+    hipLaunchKernelGGL((spade_bwd_k<1, false>), dim3(grid_for(rows * C)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy, lddy,
+                       dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr);
+  }
   return SO_LAUNCH_CHECK();
 }
 

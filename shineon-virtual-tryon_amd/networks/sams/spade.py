@@ -85,7 +85,7 @@ class SPADE(nn.Module):
             w2, b2 = ops_sams.stack_conv_params(self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
             if cache is not None:
                 cache[key] = (w2, b2)
-        gamma_beta = ops.conv2d(actv, w2, b2, 1, self.mlp_gamma.padding)
+        gamma_beta = ops.conv2d(actv, w2, b2, 1, self.mlp_gamma.padding, bias_grad_hint=True)
         kind, param = then_act if then_act is not None else ("none", 0.0)
         return ops_sams.spade_modulate(normalized, gamma_beta, kind, param)
 

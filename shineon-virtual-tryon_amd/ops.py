@@ -300,8 +300,10 @@ class _Conv2dFn(torch.autograd.Function):
     channels are computed as op = ceil4(o) columns of which the last op - o are exactly zero."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0):
+    def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0,
+                bias_grad_hint=False):
         L = lib()
+        ctx.bias_hint = bool(bias_grad_hint)
         if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
             # the backward pass evaluates act' from the OUTPUT, which only sign-preserving piecewise-linear maps allow
             raise ValueError("conv2d fuses ReLU / LeakyReLU only")
@@ -336,6 +338,9 @@ class _Conv2dFn(torch.autograd.Function):
         L = lib()
         xr, w, y = ctx.saved_tensors
         stride, pad, act, i, cp, op, has_bias, wshape, zero_bias_grad, act_param = ctx.cfg
+        # bias_grad_hint: the only consumer of the output (ops_sams._SpadeFn) reduces its gradient's columns while it
+        # writes it and hands the sums over on the gradient tensor itself
+        hint = getattr(dy, "_so_bias_grad", None) if ctx.bias_hint else None
         o, _, r, s = wshape
         n, _, h, wd = xr.shape
         dy = to_rows(dy, cpad=op) if op != o else _dense_rows(dy)  # [rows][op], pad columns zero
@@ -382,7 +387,13 @@ class _Conv2dFn(torch.autograd.Function):
                         check(L.so_copy2d(dwp.data_ptr(), cp, i, dwd.data_ptr(), i, i, o * r * s, 0, _stream()), "copy2d")
                         dw_ = dwd.permute(0, 3, 1, 2)
             if need_b:
-                if zero_bias_grad:
+                if hint is not None and op == wshape[0] and act == ACT_NONE and hint.numel() == wshape[0]:
+                    if b_direct is not None:
+                        check(L.so_axpby(hint.data_ptr(), 1.0, b_direct.grad.data_ptr(), 1.0, wshape[0], _stream()), "axpby")
+                        keep.append(hint)
+                    else:
+                        db_ = hint
+                elif zero_bias_grad:
                     # a bias in front of Instance/BatchNorm has an analytically zero gradient (the norm removes any
                     # per-channel constant); the reference computes round-off noise there.  Write the exact zero.
                     if b_direct is None:
@@ -427,16 +438,16 @@ class _Conv2dFn(torch.autograd.Function):
             fork.join()
         elif need_w or need_b:
             dw, db = weight_grads(lane=0)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False,
-           act_param=0.0):
+           act_param=0.0, bias_grad_hint=False):
     """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
     output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
     act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
     (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel."""
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param, bias_grad_hint)
 
 
 # ------------------------------------------------------------------------------------------------

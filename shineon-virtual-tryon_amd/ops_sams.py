@@ -82,9 +82,20 @@ class _SpadeFn(torch.autograd.Function):
         n, c, h, w = nrm.shape
         dgb = nhwc_empty(n, h, w, 2 * c, nrm.device)
         dn = nhwc_empty(n, h, w, c, nrm.device)
-        check(lib().so_spade_bwd(nrm.data_ptr(), _ld(nrm), gb.data_ptr(), _ld(gb), gb.data_ptr() + 4 * c, _ld(gb),
-                                 dy.data_ptr(), _ld(dy), dn.data_ptr(), c, dgb.data_ptr(), 2 * c, dgb.data_ptr() + 4 * c, 2 * c,
-                                 n * h * w, c, act, param, _stream()), "spade_bwd")
+        L = lib()
+        rows = n * h * w
+        nb = L.so_spade_bwd_colsum_blocks(rows, c) if _ld(nrm) % 4 == 0 and _ld(gb) % 4 == 0 and _ld(dy) % 4 == 0 else 0
+        part = torch.empty((nb, 2 * c), dtype=torch.float32, device=nrm.device) if nb else None
+        check(L.so_spade_bwd(nrm.data_ptr(), _ld(nrm), gb.data_ptr(), _ld(gb), gb.data_ptr() + 4 * c, _ld(gb),
+                             dy.data_ptr(), _ld(dy), dn.data_ptr(), c, dgb.data_ptr(), 2 * c, dgb.data_ptr() + 4 * c, 2 * c,
+                             rows, c, act, param, part.data_ptr() if nb else None, _stream()), "spade_bwd")
+        if nb:
+            # column sums of dgamma | dbeta = the bias gradient of the convolution that produced them: merged from the
+            # per-block partials (<= 1024 rows) instead of a second pass over the full gradient
+            db = torch.empty(2 * c, dtype=torch.float32, device=nrm.device)
+            ws = workspace(nrm.device, L.so_colsum_ws_floats(nb, 2 * c) * 4, lane=6)
+            check(L.so_colsum(part.data_ptr(), 2 * c, nb, 2 * c, db.data_ptr(), 0, ws.data_ptr(), _stream()), "colsum")
+            dgb._so_bias_grad = db
         return dn, dgb, None, None
 
 
