@@ -58,6 +58,8 @@ class BaseOptions:
         BaseOptions.apply_sort_inputs(opt)
         if getattr(opt, "n_frames_now", None) is None:
             opt.n_frames_now = getattr(opt, "n_frames_total", 1)
+        if hasattr(opt, "encoder_input") and opt.encoder_input is None:  # SamsModel.apply_default_encoder_input
+            opt.encoder_input = opt.person_inputs[0]
         self.opt = opt
         return opt
 
