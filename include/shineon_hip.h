@@ -270,8 +270,11 @@ int so_grid_sample_bwd(const float* in, const float* grid, const float* dout, fl
 /* Resample2d of the flownet2 submodule (unet_mask_model.py:115-117): out = bilinear(in, pixel + flow) */
 int so_resample2d_fwd(const float* in, const float* flow, float* out, int Nb, int C, int H, int W,
                       void* stream);
+/* backward: din (optional, overwritten) is a scatter-add; it is accumulated in 64-bit fixed point (integer atomics are
+ * associative), so the result is bit-identical from run to run.  ws: so_resample2d_bwd_ws_floats floats, 8-byte aligned. */
+long long so_resample2d_bwd_ws_floats(int Nb, int C, int H, int W);
 int so_resample2d_bwd(const float* in, const float* flow, const float* dout, float* din, float* dflow,
-                      int Nb, int C, int H, int W, void* stream);
+                      int Nb, int C, int H, int W, float* ws, void* stream);
 
 /* ---- dataset-side tensor preparation + inter-stage image wire format (csrc/dataprep.hip) ---------------- */
 

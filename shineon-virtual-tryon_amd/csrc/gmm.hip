@@ -500,13 +500,49 @@ __global__ __launch_bounds__(256) void resample2d_fwd_k(const float* __restrict_
   }
 }
 
+// The input gradient of Resample2d is a scatter-add (several output pixels may sample the same input pixel).  Float
+// atomics would make the result depend on the order the hardware retires them; instead every contribution is rounded to
+// a fixed-point grid (2^-42 of max|dout|, far below an fp32 ulp of the result) and summed with 64-bit INTEGER atomics,
+// which are associative: the gradient is bit-identical from run to run.  At most 4*H*W < 2^20 contributions of
+// magnitude <= max|dout| meet in one accumulator, so |sum| < 2^62.
+__global__ __launch_bounds__(256) void maxabs_partial_k(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) m = fmaxf(m, fabsf(x[i]));
+  m = so_wave_max(m);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void maxabs_final_k(const float* __restrict__ part, unsigned n, float* __restrict__ scale) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (unsigned i = threadIdx.x; i < n; i += 256u) m = fmaxf(m, part[i]);
+  m = so_wave_max(m);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    scale[0] = mx > 0.f ? 4398046511104.0f / mx : 0.f;  // 2^42 / max|dout|
+    scale[1] = mx > 0.f ? mx / 4398046511104.0f : 0.f;
+  }
+}
+
+__device__ __forceinline__ void fixed_add(long long* q, float v, float scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(q), (unsigned long long)__float2ll_rn(v * scale));
+}
+
 __global__ __launch_bounds__(256) void resample2d_bwd_k(const float* __restrict__ in,
                                                         const float* __restrict__ flow,
                                                         const float* __restrict__ dout,
-                                                        float* __restrict__ din,
-                                                        float* __restrict__ dflow, unsigned Nb,
-                                                        unsigned C, unsigned H, unsigned W) {
+                                                        long long* __restrict__ acc,
+                                                        float* __restrict__ dflow, const float* __restrict__ scale_p,
+                                                        unsigned Nb, unsigned C, unsigned H, unsigned W) {
   const unsigned total = Nb * H * W;
+  const float scale = acc ? scale_p[0] : 0.f;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned b = idx / (H * W), pix = idx - b * H * W;
     const unsigned y = pix / W, x = pix - y * W;
@@ -524,12 +560,12 @@ __global__ __launch_bounds__(256) void resample2d_bwd_k(const float* __restrict_
       const float vBL = p[(size_t)yB * W + xL], vBR = p[(size_t)yB * W + xR];
       gfx += go * ((1.f - bt) * (vTR - vTL) + bt * (vBR - vBL));
       gfy += go * ((1.f - a) * (vBL - vTL) + a * (vBR - vTR));
-      if (din) {
-        float* q = din + ((size_t)b * C + c) * H * W;
-        atomicAdd(q + (size_t)yT * W + xL, go * (1.f - a) * (1.f - bt));
-        atomicAdd(q + (size_t)yT * W + xR, go * a * (1.f - bt));
-        atomicAdd(q + (size_t)yB * W + xL, go * (1.f - a) * bt);
-        atomicAdd(q + (size_t)yB * W + xR, go * a * bt);
+      if (acc) {
+        long long* q = acc + ((size_t)b * C + c) * H * W;
+        fixed_add(q + (size_t)yT * W + xL, go * (1.f - a) * (1.f - bt), scale);
+        fixed_add(q + (size_t)yT * W + xR, go * a * (1.f - bt), scale);
+        fixed_add(q + (size_t)yB * W + xL, go * (1.f - a) * bt, scale);
+        fixed_add(q + (size_t)yB * W + xR, go * a * bt, scale);
       }
     }
     if (dflow) {
@@ -537,6 +573,13 @@ __global__ __launch_bounds__(256) void resample2d_bwd_k(const float* __restrict_
       dflow[((size_t)b * 2 + 1) * H * W + pix] = gfy;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void fixed_to_float_k(const long long* __restrict__ acc, size_t n,
+                                                        const float* __restrict__ scale_p, float* __restrict__ out) {
+  const double unit = (double)scale_p[1];
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u)
+    out[i] = (float)((double)acc[i] * unit);
 }
 
 }  // namespace
@@ -675,13 +718,36 @@ int so_resample2d_fwd(const float* in, const float* flow, float* out, int Nb, in
   return SO_LAUNCH_CHECK();
 }
 
-// din (optional) must be zero-filled by the caller; dflow optional.
+long long so_resample2d_bwd_ws_floats(int Nb, int C, int H, int W) {
+  return 2LL * Nb * C * H * W + 1024 + 8;  // int64 accumulators, max-abs partials, the two scale factors
+}
+
+// din, dflow optional.  din is overwritten (no pre-fill needed); ws: so_resample2d_bwd_ws_floats floats, 8-byte aligned.
 int so_resample2d_bwd(const float* in, const float* flow, const float* dout, float* din, float* dflow,
-                      int Nb, int C, int H, int W, void* stream) {
+                      int Nb, int C, int H, int W, float* ws, void* stream) {
   const long long total = (long long)Nb * H * W;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL(resample2d_bwd_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
-                     flow, dout, din, dflow, (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W);
+  hipStream_t st = (hipStream_t)stream;
+  long long* acc = nullptr;
+  float* scale = nullptr;
+  const size_t n = (size_t)Nb * C * H * W;
+  if (din) {
+    if (!ws || (((uintptr_t)ws) & 7)) return SO_ERR_ALIGN;
+    acc = reinterpret_cast<long long*>(ws);
+    float* part = ws + 2 * n;
+    scale = part + 1024;
+    int nb = grid_for((long long)n);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(maxabs_partial_k, dim3(nb), dim3(256), 0, st, dout, n, part);
+    hipLaunchKernelGGL(maxabs_final_k, dim3(1), dim3(256), 0, st, (const float*)part, (unsigned)nb, scale);
+    hipError_t e = hipMemsetAsync(acc, 0, n * sizeof(long long), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(resample2d_bwd_k, dim3(grid_for(total)), dim3(256), 0, st, in, flow, dout, acc, dflow, (const float*)scale,
+                     (unsigned)Nb, (unsigned)C, (unsigned)H, (unsigned)W);
+  if (din)
+    hipLaunchKernelGGL(fixed_to_float_k, dim3(grid_for((long long)n)), dim3(256), 0, st, (const long long*)acc, n,
+                       (const float*)scale, din);
   return SO_LAUNCH_CHECK();
 }
 

@@ -1154,15 +1154,16 @@ class _Resample2dFn(torch.autograd.Function):
         b, c, h, w = inp.shape
         dout = to_nchw(dout)
         din = dflow = None
+        L = lib()
         if ctx.needs_input_grad[0]:
             din = torch.empty_like(inp)
-            check(lib().so_fill(din.data_ptr(), din.numel(), 0.0, _stream()), "fill")
         if ctx.needs_input_grad[1]:
             dflow = torch.empty_like(flow)
+        ws = workspace(inp.device, L.so_resample2d_bwd_ws_floats(b, c, h, w) * 4, lane=7)
         check(
-            lib().so_resample2d_bwd(inp.data_ptr(), flow.data_ptr(), dout.data_ptr(),
-                                    din.data_ptr() if din is not None else None,
-                                    dflow.data_ptr() if dflow is not None else None, b, c, h, w, _stream()),
+            L.so_resample2d_bwd(inp.data_ptr(), flow.data_ptr(), dout.data_ptr(),
+                                din.data_ptr() if din is not None else None,
+                                dflow.data_ptr() if dflow is not None else None, b, c, h, w, ws.data_ptr(), _stream()),
             "resample2d_bwd",
         )
         return din, dflow
