@@ -3,7 +3,7 @@
     SHINEON_AUTOTUNE=2 SHINEON_PLANS=none python tools/make_plans.py [out.txt]
 
 Every layer shape of the configurations the tests and bench.py run (BASELINE configs at bs = 1 / 2 / 4 / 8, the
-n_frames = 3 and n_frames = 5 U-Nets) is seen once eagerly; in thorough mode each (tile, waves, split-K) candidate is
+n_frames = 3 and n_frames = 5 U-Nets, the SAMS-GAN's default networks at bs = 4 / 1) is seen once eagerly; in thorough mode each (tile, waves, split-K) candidate is
 timed on a warmed-up chip, six launches each, and the fastest is kept.  The file makes the kernel choice - hence the
 split-K summation order, hence the bit pattern of every result - the same in every process that loads it.
 """
@@ -60,6 +60,22 @@ def main():
         before = L.so_igemm_plan_count()
         one_step(model, batch)
         print(f"{kind} {hp} {b}: +{L.so_igemm_plan_count() - before} plans", flush=True)
+        del model
+        torch.cuda.empty_cache()
+    # SAMS-GAN (bench.py --config sams): the reference-default networks at bs = 4 and bs = 1, one three-optimizer step each
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+    from shineon_virtual_tryon_amd.trainer import MultiOptimizerStep
+
+    for bs in (4, 1):
+        torch.manual_seed(0)
+        hp = bench.sams_hparams()
+        model = SamsModel(hp).to(dev).train()
+        model.global_step = 1
+        batch = synthetic_batch(bs, dev, n_frames=hp.n_frames_total)
+        before = L.so_igemm_plan_count()
+        MultiOptimizerStep(model, model.configure_optimizers()[0])(batch, 0)
+        torch.cuda.synchronize()
+        print(f"sams bs={bs}: +{L.so_igemm_plan_count() - before} plans", flush=True)
         del model
         torch.cuda.empty_cache()
     n = L.so_igemm_plans_save(out.encode())
