@@ -329,3 +329,54 @@ def test_sams_spectral_weight_power_iteration_converges_to_the_top_singular_valu
     u0 = sd["c.weight_u"].clone()
     so.spectral_weight(sd, "c", training=False)  # eval: no power iteration
     assert torch.equal(u0, sd["c.weight_u"])
+
+
+def test_sams_oracle_known_answers():
+    """Analytic checks of the SAMS oracle that need no golden: SPADE with zero modulation weights is the bare
+    parameter-free norm; the generator layout of the default options; the rotated previous-frame order and the
+    previous-label-map window of `get_prev_frames_and_maps` (sams_model.py:255-270); split_predictions' nesting."""
+    import argparse
+
+    from oracle import sams_oracle as so
+
+    torch.manual_seed(0)
+    hp = argparse.Namespace(norm_G="spectralspadesyncbatch3x3", activation="relu")
+    x = torch.randn(3, 6, 8, 5) * 2 + 1
+    sd = {"s.param_free_norm.running_mean": torch.zeros(6), "s.param_free_norm.running_var": torch.ones(6),
+          "s.mlp_shared.0.weight": torch.randn(128, 4, 3, 3), "s.mlp_shared.0.bias": torch.randn(128),
+          "s.mlp_gamma.weight": torch.zeros(6, 128, 3, 3), "s.mlp_gamma.bias": torch.zeros(6),
+          "s.mlp_beta.weight": torch.zeros(6, 128, 3, 3), "s.mlp_beta.bias": torch.zeros(6)}
+    y = so.spade(sd, "s", x, torch.randn(3, 4, 32, 20), hp, training=True)
+    assert torch.allclose(y.mean(dim=(0, 2, 3)), torch.zeros(6), atol=1e-6)
+    assert torch.allclose(y.var(dim=(0, 2, 3), unbiased=False), torch.ones(6), atol=1e-4)
+    assert not torch.equal(sd["s.param_free_norm.running_mean"], torch.zeros(6))  # training mode moved the statistics
+    # default generator: conv + 4 x (block, down) | 3 middle | 4 x (up, block) + conv
+    dflt = argparse.Namespace(ngf_base=2, ngf_pow_outer=6, ngf_pow_inner=10, ngf_pow_step=1, num_middle=3)
+    enc, mid, dec = so.generator_layout(dflt)
+    assert [k for k, _ in enc] == ["conv"] + ["block", "down"] * 4 and mid == [0, 1, 2]
+    assert [k for k, _ in dec] == ["up", "block"] * 4 + ["conv"] and dec[-1][1] == 8
+    # a power step that overshoots adds one extra block on each side (sams_generator.py:150-157,194-208)
+    odd = argparse.Namespace(ngf_base=2, ngf_pow_outer=3, ngf_pow_inner=6, ngf_pow_step=2, num_middle=1)
+    enc, _, dec = so.generator_layout(odd)
+    assert [k for k, _ in enc].count("block") == 3 and [k for k, _ in dec].count("block") == 3
+    # previous frames: (f+1 .. f+n-1) mod n; previous label maps: zero padding + enc[:, n-1-f : -1]
+    n, b = 5, 1
+    hp5 = argparse.Namespace(n_frames_total=n, n_frames_now=None, person_inputs=["flow"], cloth_inputs=[], encoder_input="flow",
+                             flow_warp=False)
+    oracle = so.SamsOracle({}, hp5)
+    enc_maps = torch.arange(n, dtype=torch.float32).reshape(1, n, 1, 1, 1).expand(b, n, 2, 2, 2).clone()
+    frames = [torch.full((b, 3, 2, 2), float(10 + i)) for i in range(n)]
+    for f, want_frames, want_maps in ((0, [11, 12, 13, 14], [0, 0, 0, 0]), (3, [14, 10, 11, 12], [0, 1, 2, 3]),
+                                      (4, [10, 11, 12, 13], [0, 1, 2, 3])):
+        pf, pm = oracle.prev_frames_and_maps({"flow": enc_maps}, f, frames)
+        assert [int(v) for v in pf[0, :, 0, 0, 0]] == want_frames, (f, pf[0, :, 0, 0, 0])
+        got = [int(v) for v in pm[0, :, 0, 0, 0]]
+        start = n - 1 - f
+        assert got == [0] * start + list(range(start, n - 1)), (f, got)
+        assert f != 3 or got == [0, 1, 2, 3]  # NOT [0, 0, 1, 2]: the window starts at n-1-f, the reference's indexing
+    with pytest.raises(IndexError):
+        so.SamsOracle({}, argparse.Namespace(n_frames_total=1, n_frames_now=None, person_inputs=["flow"], cloth_inputs=[],
+                                             encoder_input="flow")).prev_frames_and_maps({"flow": enc_maps}, 0, frames)
+    t = torch.arange(8.0).reshape(4, 2)
+    fake, real = so.split_predictions([[t, 2 * t], t])
+    assert torch.equal(fake[0][1], 2 * t[:2]) and torch.equal(real[0][0], t[2:]) and torch.equal(real[1], t[2:])
