@@ -1,10 +1,10 @@
 """AttentiveMultiSpade: the SPADEs run in parallel on the same input, their outputs are stacked on the channel axis,
 attended (SAGAN) and reduced back with a 3x3 conv + LeakyReLU() (reference: models/networks/sams/attentive_multispade.py)."""
+from torch import nn
+
 from ... import ops
 from ..attention import ATTENTION_TYPES
 from ..layers import HipConv2d
-from torch import nn
-
 from .multispade import MultiSpade
 from .spade import SPADE
 

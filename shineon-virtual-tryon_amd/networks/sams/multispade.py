@@ -1,7 +1,6 @@
 """MultiSpade: one SPADE per label map, applied one after another (reference: models/networks/sams/multispade.py)."""
 from torch import Tensor, nn
 
-from ... import ops
 from .spade import SPADE
 
 

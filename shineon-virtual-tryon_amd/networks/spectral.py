@@ -7,7 +7,6 @@ Checkpoint layout kept: the parameter is renamed `weight_orig`, the power-iterat
 iteration (also under torch.no_grad()), eval-mode forwards use the stored vectors.
 """
 import torch
-from torch import nn
 from torch.nn import functional as F
 
 from .. import ops, ops_sams
