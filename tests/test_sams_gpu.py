@@ -218,6 +218,57 @@ def test_spade_residual_block_against_the_oracle(norm_G, fin, fout, hw, multi):
                    {"x": gx32, **g32}, {"x": gx64, **g64}, f"{norm_G} {fin}->{fout} {hw}")
 
 
+@pytest.mark.parametrize("norm_D,num_D,n_layers,keep_feats", [
+    ("spectralinstance", 2, 4, True), ("spectralbatch", 3, 3, True), ("spectralsync_batch", 1, 4, False),
+    ("spectralnone", 2, 5, True), ("spectral", 2, 2, False)])
+def test_patchgan_discriminators_against_the_oracle(norm_D, num_D, n_layers, keep_feats):
+    """MultiscaleDiscriminator (and through it NLayerDiscriminator) for every norm_D the reference accepts: all stage
+    outputs of all scales, the gradient of a weighted sum of them with respect to the input and every parameter, and
+    the buffers (u, v, BatchNorm statistics and counters) after the pass."""
+    import argparse
+
+    from oracle.procedural import shapes_of
+    from shineon_virtual_tryon_amd.networks.discriminator import MultiscaleDiscriminator
+
+    hp = sh.sams_hparams(norm_D=norm_D, num_D=num_D, n_layers_D=n_layers, ndf=8, no_ganFeat_loss=not keep_feats)
+    net = MultiscaleDiscriminator(hp)
+    sd = procedural_state_dict({"d." + k: v for k, v in shapes_of(net.state_dict()).items()})
+    net.load_state_dict({k[2:]: v for k, v in sd.items()})
+    net = net.to(DEV).train()
+    torch.manual_seed(8)
+    x = torch.randn(4, 15, 64, 48)
+    refs = []
+    for dtype in (torch.float32, torch.float64):
+        osd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in osd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+                v.requires_grad_(True)
+        xin = x.clone().to(dtype).requires_grad_(True)
+        outs = [t for scale in so.multiscale_discriminator(osd, "d", xin, hp, True) for t in scale]
+        torch.manual_seed(9)
+        ws = [torch.randn(t.shape) for t in outs]
+        sum((t * w.to(dtype)).sum() for t, w in zip(outs, ws)).backward()
+        refs.append(([t.detach() for t in outs], xin.grad, {k[2:]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}, osd))
+    dx = x.clone().to(DEV).requires_grad_(True)
+    got = [t for scale in net(dx) for t in scale]
+    assert len(got) == len(refs[0][0]) == num_D * ((n_layers + 1) if keep_feats else 1)
+    from shineon_virtual_tryon_amd import ops
+
+    sum(ops.tensor_sum(t * ops.to_rows(w.to(DEV))) for t, w in zip(got, ws)).backward()
+    (o32, gx32, g32, _), (o64, gx64, g64, sd64) = refs
+    for a, b in zip(got, o64):
+        assert (_nchw(a).double() - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-6)
+    _compare_grads({"x": dx.grad, **{k: p.grad for k, p in net.named_parameters() if p.grad is not None}},
+                   {"x": gx32, **g32}, {"x": gx64, **g64}, f"D {norm_D}")
+    for k, v in net.state_dict().items():
+        ref = sd64["d." + k]
+        if v.is_floating_point():
+            if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+                assert (v.cpu().double() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), k
+        else:
+            assert int(v) == int(ref), k
+
+
 # ------------------------------------------------------------------------------------------------
 # model
 # ------------------------------------------------------------------------------------------------
