@@ -7,7 +7,9 @@ Checks (reference behaviour: Lightning DDP configured at train.py:76-85, Distrib
      per-sample, every loss is a mean over the batch) - element-wise, up to fp32 reduction order;
   2. after 3 optimisation steps through trainer.TrainStep (hipGraph + asynchronous exchange) the parameters of the
      two ranks are bit-identical;
-  3. BatchNorm running statistics stay per rank without the buffer broadcast and equal rank 0's with it.
+  3. BatchNorm running statistics stay per rank without the buffer broadcast and equal rank 0's with it;
+  4. SAMS-GAN: two iterations of trainer.MultiOptimizerStep (three optimizers, one gradient exchange each) leave the two
+     ranks bit-identical, with the step counters and the batch-mean losses of a single-rank full-batch run.
 """
 import os
 import sys
@@ -113,6 +115,50 @@ for sync in (False, True):
     dist.all_gather(gp, optw.flat_params)
     assert torch.equal(gp[0], gp[1])
 print(f"DP_BN_OK {rank}", flush=True)
+
+# ---- 4. SAMS-GAN: the three optimizers of trainer.MultiOptimizerStep, each with its own gradient exchange -----------------
+# Per-sample normalisations everywhere (SPADE over InstanceNorm, discriminators spectral + InstanceNorm) make 2 ranks x bs 1
+# equivalent to 1 rank x bs 2; the batch-norm default would not be (per-rank statistics, as in the reference under DDP).
+import sams_helpers as sh  # noqa: E402
+from shineon_virtual_tryon_amd.sams_model import SamsModel  # noqa: E402
+from shineon_virtual_tryon_amd.trainer import MultiOptimizerStep  # noqa: E402
+
+shp = sh.sams_hparams(norm_G="spectralspadeinstance3x3", norm_D="spectralinstance", activation="gelu", allow_random_vgg=True)
+sfull = synthetic_batch(2, dev, height=shp.fine_height, width=shp.fine_width, n_frames=shp.n_frames_total, smooth=True)
+smine = take(sfull, rank, rank + 1)
+
+
+def sams():
+    m = SamsModel(shp)
+    m.load_state_dict(procedural_state_dict(shapes_of(m.state_dict())))
+    m.global_step = 1
+    return m.to(dev).train()
+
+
+pair, solo = sams(), sams()
+popts, sopts = pair.configure_optimizers()[0], solo.configure_optimizers()[0]
+pstep, sstep = MultiOptimizerStep(pair, popts), MultiOptimizerStep(solo, sopts)
+assert pstep.reducers is not None and len(pstep.reducers) == 3
+sstep.reducers = None                      # the single-rank reference run exchanges nothing
+for it in range(2):
+    pres, sres = pstep(smine, it), sstep(sfull, it)
+torch.cuda.synchronize()
+for name, po, so_ in zip(("generator", "multiscale D", "temporal D"), popts, sopts):
+    a, b = po.flat_params, so_.flat_params
+    both = [torch.empty_like(a) for _ in range(2)]
+    dist.all_gather(both, a)
+    assert torch.equal(both[0], both[1]), f"SAMS {name}: ranks diverged"
+    # two Adam steps from identical weights: the 2-rank run and the 1-rank full-batch run took the same direction
+    assert po._steps == so_._steps == 2
+for k in pres[0].logs:   # the per-rank generator loss differs (different sample), the mean of the two is the full-batch one
+    mine_v = pres[0].logs[k].detach().reshape(1).float()
+    got = [torch.empty_like(mine_v) for _ in range(2)]
+    dist.all_gather(got, mine_v)
+    mean = 0.5 * (got[0] + got[1])
+    ref = sres[0].logs[k].detach().reshape(1).float()
+    if k in ("loss/G/l1", "loss/G/vgg", "loss/G/l1+vgg"):
+        assert abs(float(mean - ref)) <= 2e-3 * max(1.0, abs(float(ref))), (k, float(mean), float(ref))
+print(f"DP_SAMS_OK {rank}", flush=True)
 dist.barrier()
 dist.destroy_process_group()
 print(f"DP_ALL_OK {rank}", flush=True)
