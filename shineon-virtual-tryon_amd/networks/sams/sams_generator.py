@@ -18,7 +18,7 @@ from ..base_network import BaseNetwork
 from ..layers import HipConv2d
 from .attentive_multispade import AttentiveMultiSpade
 from .multispade import MultiSpade
-from .spade import SPADE, AnySpadeResBlock
+from .spade import SPADE, AnySpadeResBlock, label_pyramid
 
 logger = logging.getLogger("logger")
 
@@ -119,10 +119,11 @@ class SamsGenerator(BaseNetwork):
         else:
             raise IndexError("SamsGenerator needs n_frames_total > 1: the reference's SamsModel indexes a frames axis that "
                              "single-frame batches do not have (models/sams_model.py:220)")
-        for layer in self.encode_layers:
-            x = layer(x, prev_maps) if isinstance(layer, AnySpadeResBlock) else layer(x)
-        for layer in self.middle_layers:
-            x = layer(x, current_labelmap_dict)
-        for layer in self.decode_layers:
-            x = layer(x, current_labelmap_dict) if isinstance(layer, AnySpadeResBlock) else layer(x)
+        with label_pyramid():  # each label map is resized to each resolution once per pass
+            for layer in self.encode_layers:
+                x = layer(x, prev_maps) if isinstance(layer, AnySpadeResBlock) else layer(x)
+            for layer in self.middle_layers:
+                x = layer(x, current_labelmap_dict)
+            for layer in self.decode_layers:
+                x = layer(x, current_labelmap_dict) if isinstance(layer, AnySpadeResBlock) else layer(x)
         return x

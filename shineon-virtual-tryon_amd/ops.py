@@ -309,7 +309,14 @@ class _Conv2dFn(torch.autograd.Function):
             raise ValueError("conv2d fuses ReLU / LeakyReLU only")
         o, i, r, s = weight.shape
         cp, op = (i + 3) // 4 * 4, (o + 3) // 4 * 4
-        xr = to_rows(x, cpad=cp) if cp != i else _dense_rows(x)
+        if cp == i:
+            xr = _dense_rows(x)
+        elif getattr(x, "_so_zero_padded", 0) == cp and _is_rows(x) and _ld(x) == cp and x.data_ptr() % 16 == 0:
+            # the caller already holds this input as a channel slice of a zero-padded cp-wide buffer (label maps shared by
+            # many SPADE convolutions): read that buffer instead of padding a private copy per convolution
+            xr = torch.as_strided(x, (x.shape[0], cp, x.shape[2], x.shape[3]), x.stride(), x.storage_offset())
+        else:
+            xr = to_rows(x, cpad=cp)
         w = _ohwi(weight, cpad=cp)
         n, _, h, wd = xr.shape
         ho = (h + 2 * pad - r) // stride + 1
