@@ -116,7 +116,8 @@ long long so_norm_ws_floats(int G, long long R, int C);
 
 /* InstanceNorm2d (G = batch, R = H*W; unet.py:136,146) / BatchNorm2d training (G = 1, R = N*H*W;
  * warp.py:15,21,29,75-84): y = (x - mean) * rstd [* gamma + beta]; mean/rstd [G][C] are outputs kept for
- * backward; running_mean/var (optional) get the momentum update with the unbiased variance. */
+ * backward; running_mean/var (optional) get the momentum update with the unbiased variance.  y = NULL: statistics
+ * only (the caller normalises inside its own pass, so_spade_norm_fwd). */
 int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
                 const float* gamma, const float* beta, float* mean, float* rstd,
                 float* running_mean, float* running_var, float momentum, float* ws, void* stream);
@@ -364,6 +365,16 @@ int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const f
 int so_spade_bwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, const float* dy, int lddy,
                  float* dn, int lddn, float* dgamma, int lddg, float* dbeta, int lddb, long long rows, int C, int act,
                  float act_param, float* colsum_part, void* stream);
+/* The same two passes with the parameter-free normalisation folded in (spade.py:80 + :89): `x` is the un-normalised
+ * activation, n = (x - mean[g][c]) * rstd[g][c], g = row / R (mean / rstd [rows / R][C] from so_norm_fwd(y = NULL)); the
+ * normalised tensor is never materialised.  dn is the gradient with respect to n: feed it to so_norm_bwd. */
+int so_spade_norm_fwd(const float* x, int ldx, const float* mean, const float* rstd, long long R, const float* gamma, int ldg,
+                      const float* beta, int ldb, float* y, int ldy, long long rows, int C, int act, float act_param,
+                      void* stream);
+int so_spade_norm_bwd(const float* x, int ldx, const float* mean, const float* rstd, long long R, const float* gamma, int ldg,
+                      const float* beta, int ldb, const float* dy, int lddy, float* dn, int lddn, float* dgamma, int lddg,
+                      float* dbeta, int lddb, long long rows, int C, int act, float act_param, float* colsum_part,
+                      void* stream);
 /* colsum_part (optional): [so_spade_bwd_colsum_blocks(rows, C)][2C] per-block column sums of dgamma | dbeta - summed over
  * the blocks they are the bias gradient of the convolution that produced gamma | beta.  0 blocks: C not eligible. */
 int so_spade_bwd_colsum_blocks(long long rows, int C);

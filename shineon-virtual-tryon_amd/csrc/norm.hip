@@ -326,7 +326,7 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
     }
   }
   __syncthreads();
-  if (!live) return;
+  if (!live || !y) return;  // y == nullptr: statistics only
   const float m = bmean[tx], rs = brstd[tx];
   const float ga = gamma ? gamma[col] : 1.f, be = gamma ? beta[col] : 0.f;
   float* by = y + (size_t)g * R * ldy + col;
@@ -441,6 +441,7 @@ int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, 
   dim3 g2(so_cdiv(C, 16), G);
   hipLaunchKernelGGL(stats_final_k, g2, dim3(1024), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
                      running_mean, running_var, momentum);
+  if (!y) return SO_LAUNCH_CHECK();  // statistics only: the caller normalises inside its own pass (so_spade_norm_fwd)
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && al16(x) && al16(y) && al16(mean) && al16(rstd))
     hipLaunchKernelGGL(norm_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y, ldy,

@@ -97,17 +97,33 @@ __global__ __launch_bounds__(256) void add_k(const float* __restrict__ a, int ld
 }
 
 // ------------------------------------------------------------------ SPADE modulation
+// mean != nullptr: `nrm` is the UN-normalised activation x and n = (x - mean[g][c]) * rstd[g][c] with g = row / R
+// (batch norm: one group; instance norm: one group per sample) - the normalised tensor is never written to HBM.
+template <int VEC>
+__device__ __forceinline__ float __attribute__((ext_vector_type(VEC)))
+spade_normalised(const float* __restrict__ nrm, int ldn, unsigned row, unsigned c0, const float* __restrict__ mean,
+                 const float* __restrict__ rstd, unsigned R, unsigned C) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  vec_t n = *reinterpret_cast<const vec_t*>(nrm + (size_t)row * ldn + c0);
+  if (mean) {
+    const size_t s = (size_t)(row / R) * C + c0;
+    n = (n - *reinterpret_cast<const vec_t*>(mean + s)) * *reinterpret_cast<const vec_t*>(rstd + s);
+  }
+  return n;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void spade_fwd_k(const float* __restrict__ nrm, int ldn, const float* __restrict__ gamma,
                                                    int ldg, const float* __restrict__ beta, int ldb,
                                                    float* __restrict__ y, int ldy, unsigned rows, unsigned C, int act,
-                                                   float param) {
+                                                   float param, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, unsigned R) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const unsigned CQ = C / VEC;
   const unsigned total = rows * CQ;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / CQ, c0 = (idx - row * CQ) * VEC;
-    const vec_t n = *reinterpret_cast<const vec_t*>(nrm + (size_t)row * ldn + c0);
+    const vec_t n = spade_normalised<VEC>(nrm, ldn, row, c0, mean, rstd, R, C);
     const vec_t g = *reinterpret_cast<const vec_t*>(gamma + (size_t)row * ldg + c0);
     const vec_t b = *reinterpret_cast<const vec_t*>(beta + (size_t)row * ldb + c0);
     vec_t o;
@@ -126,7 +142,9 @@ __global__ __launch_bounds__(256) void spade_bwd_k(const float* __restrict__ nrm
                                                    int ldg, const float* __restrict__ beta, int ldb,
                                                    const float* __restrict__ dy, int lddy, float* __restrict__ dn, int lddn,
                                                    float* __restrict__ dgamma, int lddg, float* __restrict__ dbeta, int lddb,
-                                                   unsigned rows, unsigned C, int act, float param, float* __restrict__ part) {
+                                                   unsigned rows, unsigned C, int act, float param, float* __restrict__ part,
+                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                   unsigned R) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const unsigned CQ = C / VEC;
   const unsigned total = rows * CQ;
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(256) void spade_bwd_k(const float* __restrict__ nrm
   for (int i = 0; i < VEC; ++i) { sg[i] = 0.f; sb[i] = 0.f; }
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     const unsigned row = idx / CQ, c0 = (idx - row * CQ) * VEC;
-    const vec_t n = *reinterpret_cast<const vec_t*>(nrm + (size_t)row * ldn + c0);
+    const vec_t n = spade_normalised<VEC>(nrm, ldn, row, c0, mean, rstd, R, C);
     const vec_t g = *reinterpret_cast<const vec_t*>(gamma + (size_t)row * ldg + c0);
     const vec_t b = *reinterpret_cast<const vec_t*>(beta + (size_t)row * ldb + c0);
     const vec_t d = *reinterpret_cast<const vec_t*>(dy + (size_t)row * lddy + c0);
@@ -478,19 +496,6 @@ int so_add(const float* a, int lda, const float* b, int ldb, float* y, int ldy, 
   return SO_LAUNCH_CHECK();
 }
 
-int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, float* y, int ldy,
-                 long long rows, int C, int act, float act_param, void* stream) {
-  if (rows <= 0 || C <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  if (vec4(C, ldn, ldy, nrm, y) && vec4(C, ldg, ldb, gamma, beta))
-    hipLaunchKernelGGL(spade_fwd_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, y, ldy,
-                       (unsigned)rows, (unsigned)C, act, act_param);
-  else
-    hipLaunchKernelGGL(spade_fwd_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, y, ldy,
-                       (unsigned)rows, (unsigned)C, act, act_param);
-  return SO_LAUNCH_CHECK();
-}
-
 static inline bool spade_colsum_ok(int C) { return (C & 3) == 0 && C / 4 <= 256 && ((C / 4) & (C / 4 - 1)) == 0; }
 
 int so_spade_bwd_colsum_blocks(long long rows, int C) {
@@ -499,26 +504,59 @@ int so_spade_bwd_colsum_blocks(long long rows, int C) {
   return b > 1024 ? 1024 : b;
 }
 
+int so_spade_norm_fwd(const float* x, int ldx, const float* mean, const float* rstd, long long R, const float* gamma, int ldg,
+                      const float* beta, int ldb, float* y, int ldy, long long rows, int C, int act, float act_param,
+                      void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (mean && (R <= 0 || rows % R)) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned Ru = mean ? (unsigned)R : 1u;
+  if (vec4(C, ldx, ldy, x, y) && vec4(C, ldg, ldb, gamma, beta) && (!mean || (al16(mean) && al16(rstd))))
+    hipLaunchKernelGGL(spade_fwd_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, st, x, ldx, gamma, ldg, beta, ldb, y, ldy,
+                       (unsigned)rows, (unsigned)C, act, act_param, mean, rstd, Ru);
+  else
+    hipLaunchKernelGGL(spade_fwd_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, x, ldx, gamma, ldg, beta, ldb, y, ldy,
+                       (unsigned)rows, (unsigned)C, act, act_param, mean, rstd, Ru);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_spade_fwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, float* y, int ldy,
+                 long long rows, int C, int act, float act_param, void* stream) {
+  return so_spade_norm_fwd(nrm, ldn, nullptr, nullptr, 0, gamma, ldg, beta, ldb, y, ldy, rows, C, act, act_param, stream);
+}
+
+int so_spade_norm_bwd(const float* x, int ldx, const float* mean, const float* rstd, long long R, const float* gamma, int ldg,
+                      const float* beta, int ldb, const float* dy, int lddy, float* dn, int lddn, float* dgamma, int lddg,
+                      float* dbeta, int lddb, long long rows, int C, int act, float act_param, float* colsum_part,
+                      void* stream) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (mean && (R <= 0 || rows % R)) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned Ru = mean ? (unsigned)R : 1u;
+  const bool v4 = vec4(C, ldx, lddy, x, dy) && vec4(C, ldg, ldb, gamma, beta) && vec4(C, lddn, lddg, dn, dgamma) &&
+                  vec4(C, lddb, lddb, dbeta, dbeta) && (!mean || (al16(mean) && al16(rstd)));
+  if (colsum_part) {
+    if (!v4 || !spade_colsum_ok(C)) return SO_ERR_ALIGN;
+    hipLaunchKernelGGL((spade_bwd_k<4, true>), dim3(so_spade_bwd_colsum_blocks(rows, C)), dim3(256), 0, st, x, ldx, gamma, ldg,
+                       beta, ldb, dy, lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param,
+                       colsum_part, mean, rstd, Ru);
+  } else if (v4) {
+    hipLaunchKernelGGL((spade_bwd_k<4, false>), dim3(grid_for(rows * C / 4)), dim3(256), 0, st, x, ldx, gamma, ldg, beta, ldb, dy,
+                       lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr,
+                       mean, rstd, Ru);
+  } else {
+    hipLaunchKernelGGL((spade_bwd_k<1, false>), dim3(grid_for(rows * C)), dim3(256), 0, st, x, ldx, gamma, ldg, beta, ldb, dy, lddy,
+                       dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr, mean,
+                       rstd, Ru);
+  }
+  return SO_LAUNCH_CHECK();
+}
+
 int so_spade_bwd(const float* nrm, int ldn, const float* gamma, int ldg, const float* beta, int ldb, const float* dy, int lddy,
                  float* dn, int lddn, float* dgamma, int lddg, float* dbeta, int lddb, long long rows, int C, int act,
                  float act_param, float* colsum_part, void* stream) {
-  if (rows <= 0 || C <= 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  const bool v4 = vec4(C, ldn, lddy, nrm, dy) && vec4(C, ldg, ldb, gamma, beta) && vec4(C, lddn, lddg, dn, dgamma) &&
-                  vec4(C, lddb, lddb, dbeta, dbeta);
-  if (colsum_part) {
-    if (!v4 || !spade_colsum_ok(C)) return SO_ERR_ALIGN;
-    hipLaunchKernelGGL((spade_bwd_k<4, true>), dim3(so_spade_bwd_colsum_blocks(rows, C)), dim3(256), 0, st, nrm, ldn, gamma, ldg,
-                       beta, ldb, dy, lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param,
-                       colsum_part);
-  } else if (v4) {
-    hipLaunchKernelGGL((spade_bwd_k<4, false>), dim3(grid_for(rows * C / 4)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy,
-                       lddy, dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr);
-  } else {
-    hipLaunchKernelGGL((spade_bwd_k<1, false>), dim3(grid_for(rows * C)), dim3(256), 0, st, nrm, ldn, gamma, ldg, beta, ldb, dy, lddy,
-                       dn, lddn, dgamma, lddg, dbeta, lddb, (unsigned)rows, (unsigned)C, act, act_param, (float*)nullptr);
-  }
-  return SO_LAUNCH_CHECK();
+  return so_spade_norm_bwd(nrm, ldn, nullptr, nullptr, 0, gamma, ldg, beta, ldb, dy, lddy, dn, lddn, dgamma, lddg, dbeta, lddb,
+                           rows, C, act, act_param, colsum_part, stream);
 }
 
 int so_avgpool3s2_fwd(const float* x, int ldx, float* y, int ldy, int Nb, int H, int W, int C, void* stream) {

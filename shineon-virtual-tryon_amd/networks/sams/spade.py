@@ -105,7 +105,6 @@ class SPADE(nn.Module):
 
     def forward(self, x, segmap, then_act=None):
         """then_act: (kind, param) of an activation applied to the result in the same pass."""
-        normalized = self.param_free_norm(x)
         seg = label_pyramid.resized(segmap, x.shape[2:])
         actv = self.mlp_shared[0](seg)
         if self.mlp_act[0] != "relu":
@@ -120,7 +119,15 @@ class SPADE(nn.Module):
                 cache[key] = (w2, b2)
         gamma_beta = ops.conv2d(actv, w2, b2, 1, self.mlp_gamma.padding, bias_grad_hint=True)
         kind, param = then_act if then_act is not None else ("none", 0.0)
-        return ops_sams.spade_modulate(normalized, gamma_beta, kind, param)
+        norm = self.param_free_norm
+        if isinstance(norm, HipInstanceNorm2d):
+            return ops_sams.spade_norm_modulate(x, gamma_beta, instance=True, eps=norm.eps, act=kind, param=param)
+        if self.training:  # batch statistics: normalisation, modulation and activation in one pass over x
+            if norm.count_batches and not norm._shared_counter:
+                norm.num_batches_tracked += 1
+            return ops_sams.spade_norm_modulate(x, gamma_beta, norm.running_mean, norm.running_var, instance=False,
+                                                momentum=norm.momentum, eps=norm.eps, act=kind, param=param)
+        return ops_sams.spade_modulate(norm(x), gamma_beta, kind, param)  # eval: running statistics
 
 
 class AnySpadeResBlock(nn.Module):

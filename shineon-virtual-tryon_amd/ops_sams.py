@@ -109,6 +109,73 @@ def spade_modulate(normalized, gamma_beta, act=ACT_NONE, param=0.0):
     return _SpadeFn.apply(normalized, gamma_beta, ACT_CODES[act] if not isinstance(act, int) else act, float(param))
 
 
+class _SpadeNormFn(torch.autograd.Function):
+    """y = act(norm(x) * (1 + gamma) + beta) with the parameter-free batch / instance norm of SPADE folded into the
+    modulation pass: statistics (so_norm_fwd without an output), then ONE pass that normalises, modulates and activates.
+    The normalised tensor is never written; the backward pass recomputes it from x and the saved statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gb, running_mean, running_var, instance, momentum, eps, act, param):
+        L = lib()
+        x, gb = to_rows(x), to_rows(gb)
+        n, c, h, w = x.shape
+        G, R = (n, h * w) if instance else (1, n * h * w)
+        mean = torch.empty((G, c), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((G, c), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
+        check(L.so_norm_fwd(x.data_ptr(), _ld(x), None, 0, G, R, c, eps, None, None, mean.data_ptr(), rstd.data_ptr(),
+                            running_mean.data_ptr() if running_mean is not None else None,
+                            running_var.data_ptr() if running_var is not None else None, momentum, ws.data_ptr(), _stream()),
+              "norm_stats")
+        y = nhwc_empty(n, h, w, c, x.device)
+        check(L.so_spade_norm_fwd(x.data_ptr(), _ld(x), mean.data_ptr(), rstd.data_ptr(), R, gb.data_ptr(), _ld(gb),
+                                  gb.data_ptr() + 4 * c, _ld(gb), y.data_ptr(), c, n * h * w, c, act, param, _stream()),
+              "spade_norm_fwd")
+        ctx.save_for_backward(x, gb, mean, rstd)
+        ctx.cfg = (G, R, act, param)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = lib()
+        x, gb, mean, rstd = ctx.saved_tensors
+        G, R, act, param = ctx.cfg
+        dy = to_rows(dy)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dgb = nhwc_empty(n, h, w, 2 * c, x.device)
+        dn = nhwc_empty(n, h, w, c, x.device)
+        nb = L.so_spade_bwd_colsum_blocks(rows, c) if _ld(x) % 4 == 0 and _ld(gb) % 4 == 0 and _ld(dy) % 4 == 0 else 0
+        part = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device) if nb else None
+        check(L.so_spade_norm_bwd(x.data_ptr(), _ld(x), mean.data_ptr(), rstd.data_ptr(), R, gb.data_ptr(), _ld(gb),
+                                  gb.data_ptr() + 4 * c, _ld(gb), dy.data_ptr(), _ld(dy), dn.data_ptr(), c, dgb.data_ptr(), 2 * c,
+                                  dgb.data_ptr() + 4 * c, 2 * c, rows, c, act, param, part.data_ptr() if nb else None, _stream()),
+              "spade_norm_bwd")
+        if nb:
+            db = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+            ws = workspace(x.device, L.so_colsum_ws_floats(nb, 2 * c) * 4, lane=6)
+            check(L.so_colsum(part.data_ptr(), 2 * c, nb, 2 * c, db.data_ptr(), 0, ws.data_ptr(), _stream()), "colsum")
+            dgb._so_bias_grad = db
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = nhwc_empty(n, h, w, c, x.device)
+            ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
+            check(L.so_norm_bwd(x.data_ptr(), _ld(x), dn.data_ptr(), c, dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
+                                None, None, None, 0, 0, ws.data_ptr(), _stream()), "norm_bwd")
+        return dx, dgb, None, None, None, None, None, None, None
+
+
+def spade_norm_modulate(x, gamma_beta, running_mean=None, running_var=None, instance=False, momentum=0.1, eps=1e-5,
+                        act=ACT_NONE, param=0.0):
+    """SPADE.forward in training mode (sams/spade.py:80-89): batch statistics (instance=False; the running statistics get
+    their momentum update) or per-sample statistics (instance=True), modulation and the following activation."""
+    _require_cuda(x)
+    if gamma_beta.shape[1] != 2 * x.shape[1]:
+        raise ValueError("gamma_beta must hold 2 * C channels")
+    return _SpadeNormFn.apply(x, gamma_beta, running_mean, running_var, bool(instance), float(momentum), float(eps),
+                              ACT_CODES[act] if not isinstance(act, int) else act, float(param))
+
+
 class _StackConvParamsFn(torch.autograd.Function):
     """(w_a, b_a, w_b, b_b) -> (cat([w_a, w_b], 0), cat([b_a, b_b])) in OHWI memory.  The gradient of the stacked tensors
     is handed back as two row blocks; parameters whose .grad lives in the optimizer's flat slab are accumulated in place."""
