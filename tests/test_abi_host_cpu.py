@@ -435,3 +435,61 @@ def test_sams_init_weights_matches_the_reference_stream(tag, kw):
         k0, p0 = next(iter(net.named_parameters()))
         assert np.array_equal(p0.detach().contiguous().numpy(), g[f"{tag}:full:{name}.{k0}"])
     assert np.array_equal(torch.rand(4).numpy(), g[f"{tag}:next_random"])
+
+
+def test_multi_optimizer_step_follows_lightnings_loop():
+    """trainer.MultiOptimizerStep on the CPU with stub optimizers: for optimizer k only ITS network's parameters require grad
+    while training_step(batch, idx, k) runs and is differentiated, the optimizers step in order 0, 1, 2, gradient accumulation
+    defers the update, frozen parameters are never switched on, and flush() puts requires_grad back."""
+    from torch import nn
+
+    from shineon_virtual_tryon_amd.pl_compat import TrainResult
+    from shineon_virtual_tryon_amd.trainer import MultiOptimizerStep
+
+    class StubOpt:
+        def __init__(self, params, log, name):
+            self.params, self.log, self.name = list(params), log, name
+            self.flat_grads = torch.zeros(sum(p.numel() for p in self.params))
+
+        def step(self, grad_scale=1.0):
+            self.log.append(("step", self.name, grad_scale, [p.grad is not None for p in self.params]))
+
+        def zero_grad(self):
+            for p in self.params:
+                p.grad = None
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.c = nn.Linear(2, 2), nn.Linear(2, 2), nn.Linear(2, 2)
+            self.frozen = nn.Linear(2, 2)
+            for p in self.frozen.parameters():
+                p.requires_grad_(False)
+            self.seen = []
+
+        def optimizer_networks(self):
+            return [self.a, self.b, self.c]
+
+        def training_step(self, batch, idx, optimizer_idx):
+            self.seen.append((optimizer_idx, [n for n, p in self.named_parameters() if p.requires_grad]))
+            x = self.frozen(batch)
+            return TrainResult((self.a(x) + self.b(x) + self.c(x)).sum().reshape(1))
+
+    log = []
+    toy = Toy()
+    opts = [StubOpt(net.parameters(), log, name) for net, name in zip(toy.optimizer_networks(), "abc")]
+    step = MultiOptimizerStep(toy, opts, accumulate=2)
+    x = torch.randn(3, 2)
+    step(x, 0)
+    assert [k for k, _ in toy.seen] == [0, 1, 2]
+    assert toy.seen[0][1] == ["a.weight", "a.bias"] and toy.seen[1][1] == ["b.weight", "b.bias"] and toy.seen[2][1] == ["c.weight", "c.bias"]
+    assert log == [] and not step.stepped                      # first micro-batch of two: gradients kept, no update
+    assert all(p.grad is not None for p in toy.a.parameters()) and all(p.grad is None for p in toy.frozen.parameters())
+    step(x, 1)
+    assert [(kind, name, scale) for kind, name, scale, _ in log] == [("step", "a", 0.5), ("step", "b", 0.5), ("step", "c", 0.5)]
+    assert all(all(flags) for *_, flags in log) and step.stepped
+    assert all(p.grad is None for net in toy.optimizer_networks() for p in net.parameters())   # zero_grad after each update
+    step.flush()
+    assert [n for n, p in toy.named_parameters() if p.requires_grad] == ["a.weight", "a.bias", "b.weight", "b.bias", "c.weight", "c.bias"]
+    with pytest.raises(ValueError):
+        MultiOptimizerStep(toy, opts[:2])
