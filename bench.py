@@ -450,8 +450,7 @@ def main():
     torch.manual_seed(420)
     cfg = args.config
     if cfg == "sams":
-        if args.batch == 4 and "--batch" not in sys.argv:
-            args.batch = 1  # five generator passes keep ~60 GB of activations per sample alive for the backward pass
+        # --batch 4 (the default) is also the reference's default for this model (sams_model.py:40): ~50 GiB of HBM
         if "--steps" not in sys.argv:
             args.steps, args.warmup = 3, 1
         run_sams(args, trainer, L)
