@@ -505,10 +505,16 @@ __global__ __launch_bounds__(256) void resample2d_fwd_k(const float* __restrict_
 // a fixed-point grid (2^-42 of max|dout|, far below an fp32 ulp of the result) and summed with 64-bit INTEGER atomics,
 // which are associative: the gradient is bit-identical from run to run.  At most 4*H*W < 2^20 contributions of
 // magnitude <= max|dout| meet in one accumulator, so |sum| < 2^62.
+// A non-finite dout must not be laundered into a finite gradient (fmaxf drops NaN, __float2ll_rn(NaN) is 0): the max pass
+// reports +inf as soon as one element is NaN or Inf, and the final pass then poisons the whole input gradient with NaN,
+// so a diverging generator shows up exactly as it would with the float scatter-add.
 __global__ __launch_bounds__(256) void maxabs_partial_k(const float* __restrict__ x, size_t n, float* __restrict__ part) {
   __shared__ float red[4];
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) m = fmaxf(m, fabsf(x[i]));
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+    const float a = fabsf(x[i]);
+    m = (a <= 3.402823466e+38f) ? fmaxf(m, a) : __int_as_float(0x7f800000);  // NaN / Inf -> +inf (sticky under fmaxf)
+  }
   m = so_wave_max(m);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) red[w] = m;
@@ -526,8 +532,9 @@ __global__ __launch_bounds__(256) void maxabs_final_k(const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    scale[0] = mx > 0.f ? 4398046511104.0f / mx : 0.f;  // 2^42 / max|dout|
-    scale[1] = mx > 0.f ? mx / 4398046511104.0f : 0.f;
+    const bool finite = mx <= 3.402823466e+38f;
+    scale[0] = (mx > 0.f && finite) ? 4398046511104.0f / mx : 0.f;  // 2^42 / max|dout|
+    scale[1] = finite ? (mx > 0.f ? mx / 4398046511104.0f : 0.f) : __int_as_float(0x7fc00000);  // non-finite dout: NaN out
   }
 }
 

@@ -101,7 +101,12 @@ class SamsModel(BaseModel):
         return opts, [self._make_step_scheduler(o) for o in opts]
 
     def batch_keys(self):
-        return sorted({"image", self.hparams.encoder_input, *self.inputs})
+        """Tensor entries of the batch this model reads: training (image, the label-map input, the person inputs, the
+        optical flow of generate_n_frames under --flow_warp) and what the reference's visualize() shows (cloth + inputs)."""
+        keys = {"image", "cloth", self.hparams.encoder_input, *self.inputs}
+        if getattr(self.hparams, "flow_warp", False):
+            keys.add("flow")
+        return sorted(keys)
 
     def require_pretrained_vgg(self):
         """Called by Trainer.fit before training: the reference trains against ImageNet VGG19 features

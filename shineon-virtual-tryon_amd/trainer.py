@@ -380,8 +380,11 @@ class MultiOptimizerStep:
     optimizer step, zero_grad.  Runs eagerly: the generator pass is five dependent forward passes whose launch count
     dwarfs a hipGraph's benefit only at toy sizes."""
 
-    def __init__(self, model, optimizers, networks=None, accumulate=1):
+    def __init__(self, model, optimizers, networks=None, accumulate=1, sync_buffers=True):
         self.model, self.optimizers = model, list(optimizers)
+        # Lightning's DDP wrapper re-broadcasts rank 0's buffers before EVERY forward (broadcast_buffers=True), i.e. once
+        # per optimizer_idx: the per-process "syncbatch" running statistics of every SPADE stay rank 0's on all ranks
+        self.sync_buffers = bool(sync_buffers) and _world() > 1 and flatten_float_buffers(model) is not None
         self.networks = list(networks) if networks is not None else model.optimizer_networks()
         if len(self.networks) != len(self.optimizers):
             raise ValueError("one network per optimizer")
@@ -411,6 +414,8 @@ class MultiOptimizerStep:
         update = self._micro % self.accumulate == 0
         for idx, opt in enumerate(self.optimizers):
             self._only(idx)
+            if self.sync_buffers:
+                broadcast_buffers(self.model)
             result = self.model.training_step(batch, batch_idx, idx)
             result.minimize.sum().backward()
             if update:
@@ -605,7 +610,8 @@ class Trainer:
                     batch = _to_device(batch, self.device)
                     model.global_step = self.global_step
                     if step is None and multi:
-                        step = MultiOptimizerStep(model, self.optimizers, accumulate=self.accumulate)
+                        step = MultiOptimizerStep(model, self.optimizers, accumulate=self.accumulate,
+                                                  sync_buffers=self.broadcast_bn_buffers)
                     elif step is None:
                         step = TrainStep(model, self.optimizer, batch, graph=self.graph, overlap=self.overlap,
                                          accumulate=self.accumulate, sync_buffers=self.broadcast_bn_buffers)
@@ -632,6 +638,11 @@ class Trainer:
         except KeyboardInterrupt:
             raise SystemExit(130)
         except Exception as e:  # mirror train.py:63-66: checkpoint, then re-raise
+            try:  # land the exchange + Adam still in flight (overlap=True) and restore the requires_grad pattern, so the
+                if step is not None:  # checkpoint holds the parameters / moments of the step global_step counts
+                    step.flush()
+            except Exception:  # noqa: BLE001 - the original error is the one to report
+                logger.exception("flush before the failure checkpoint failed; the checkpoint may lag one step")
             torch.cuda.synchronize()
             self.save_checkpoint(osp.join(ckpt_dir, f"interrupted_by_{type(e).__name__}.ckpt"))
             raise

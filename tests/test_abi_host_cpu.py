@@ -239,14 +239,23 @@ got = [torch.zeros(5, dtype=torch.long) for _ in range(2)]
 dist.all_gather(got, torch.tensor(seen))
 assert sorted(torch.cat(got).tolist()) == list(range(10))
 dist.barrier()
+dist.destroy_process_group()
 print("DP_OK", rank)
 """
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def test_data_parallel_reducer_world2_gloo(tmp_path):
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", GLOO_SOCKET_IFNAME="lo")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
