@@ -121,6 +121,13 @@ def grad_checksums(module):
     return {k: checksums(p.grad) for k, p in module.named_parameters() if p.grad is not None}
 
 
+def grad_samples(module, stride=97):
+    """Every `stride`-th element (flattened OIHW order) of every parameter gradient: ties the oracle's (and the HIP path's)
+    gradients to the reference's ELEMENT-WISE, not only through three checksums per tensor."""
+    return {k: p.grad.detach().contiguous().reshape(-1)[::stride].clone().numpy()
+            for k, p in module.named_parameters() if p.grad is not None}
+
+
 # ------------------------------------------------------------------------------------------------
 # generators
 # ------------------------------------------------------------------------------------------------
@@ -157,6 +164,8 @@ def gen_warp(out):
     }
     for k, v in grad_checksums(model).items():
         data["gcs:" + k] = v
+    for k, v in grad_samples(model).items():
+        data["gs97:" + k] = v
     np.savez_compressed(os.path.join(out, "warp_model.npz"), **data)
     print("warp_model.npz loss", data["loss"])
 
@@ -183,6 +192,8 @@ def gen_unet(out):
             data[name + "_cs"] = checksums(t)
         for k, v in grad_checksums(model.unet).items():
             data["gcs:unet." + k] = v
+        for k, v in grad_samples(model.unet).items():
+            data["gs97:unet." + k] = v
         np.savez_compressed(os.path.join(out, f"unet_mask_{tag}.npz"), **data)
         print(f"unet_mask_{tag}.npz", {k: float(v) for k, v in data.items() if k.startswith("log:")})
 
@@ -212,6 +223,8 @@ def gen_unet_nframes(out):
         data[name + "_cs"] = checksums(t)
     for k, v in grad_checksums(model.unet).items():
         data["gcs:unet." + k] = v
+    for k, v in grad_samples(model.unet, 397).items():
+        data["gs397:unet." + k] = v
     np.savez_compressed(os.path.join(out, "unet_mask_n3_flow.npz"), **data)
     print("unet_mask_n3_flow.npz", {k: float(v) for k, v in data.items() if k.startswith("log:")})
 
@@ -480,6 +493,7 @@ def gen_sams(out):
             grads = {k: p.grad for k, p in nets[idx].named_parameters() if p.grad is not None}
             for k, g in grads.items():
                 data[f"gcs{idx}:{own}.{k}"] = checksums(g)
+                data[f"gs{idx}:{own}.{k}"] = g.detach().contiguous().reshape(-1)[::97].clone().numpy()
             # a few gradients in full: smallest tensors of the step plus the first conv
             for k in sorted(grads, key=lambda k: grads[k].numel())[:6] + [next(iter(grads))]:
                 data[f"grad{idx}:{own}.{k}"] = grads[k].numpy()

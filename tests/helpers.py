@@ -46,6 +46,27 @@ def assert_checksums(t, ref_cs, rel, what="", floor=1e-5):
     assert abs(cs[2] - ref_cs[2]) <= 2 * rel * l2 * l2 + 2 * floor * l2 + floor * floor, f"{what}: sq-sum {cs[2]} vs {ref_cs[2]}"
 
 
+def assert_grad_samples(get_grad, g, prefix, rel, what="", floor=2e-7):
+    """Element-wise pin of gradients against the reference's own: the golden holds every N-th element (flattened OIHW order,
+    key `<prefix><name>`, N encoded in the prefix as gs<N>:) of every parameter gradient of the reference's backward pass.
+    |ours - ref| <= rel * max|ref| + floor per tensor (floor: gradients that are analytically zero - a bias in front of a
+    normalisation - hold round-off noise of ~1e-9 in the reference).  Returns the number of tensors compared."""
+    import re
+
+    stride = int(re.match(r"gs(\d+)", prefix).group(1)) if re.match(r"gs(\d+)", prefix) else 97
+    keys = [k for k in g.files if k.startswith(prefix)]
+    bad = []
+    for k in keys:
+        ref = np.asarray(g[k], dtype=np.float64)
+        got = get_grad(k[len(prefix):]).detach().cpu().contiguous().reshape(-1)[::stride].double().numpy()
+        assert got.shape == ref.shape, (what, k, got.shape, ref.shape)
+        err, big = np.abs(got - ref).max(), np.abs(ref).max()
+        if err > rel * big + floor:
+            bad.append(f"{k[len(prefix):]}: {err:.3e} vs max {big:.3e}")
+    assert not bad, f"{what}: {len(bad)}/{len(keys)} gradient tensors differ element-wise from the reference: " + "; ".join(bad[:8])
+    return len(keys)
+
+
 def synthetic_cpu_batch(bs=2):
     from shineon_virtual_tryon_amd.data import synthetic_batch
 

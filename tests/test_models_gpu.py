@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, golden_state, load_golden, make_namespace,
+from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, assert_grad_samples, golden_state, load_golden, make_namespace,
                      oracle, strided, synthetic_cpu_batch, unet_hp)
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +49,13 @@ def test_warp_model_vs_reference_golden(cuda):
     params = dict(model.named_parameters())
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=k)
+    # every 97th element of every gradient vs the REFERENCE's own backward pass.  The person-branch extractor's fp32
+    # gradients are ill-conditioned (the reference itself sits up to 5.9e-2 of max from its fp64 evaluation at bs=4,
+    # tests/test_parity_bs4_gpu.py): those tensors get the looser bound
+    assert_grad_samples(lambda k: params[k].grad, {k: g[k] for k in g.files if "extractionA" not in k}, "gs97:", rel=5e-3,
+                        what="warp vs reference")
+    assert_grad_samples(lambda k: params[k].grad, {k: g[k] for k in g.files if "extractionA" in k}, "gs97:", rel=8e-2,
+                        what="warp person branch vs reference")
     assert_close(model.extractionA.model[2].running_mean, g["bn_rm_A2"], atol=1e-5, what="BN running mean")
     assert_close(model.extractionA.model[2].running_var, g["bn_rv_A2"], atol=1e-5, what="BN running var")
     assert_close(model.regression.conv[10].running_var, g["bn_rv_R10"], atol=1e-4, what="BN running var R10")
@@ -77,6 +84,11 @@ def test_unet_mask_model_vs_reference_golden(cuda, variant):
     for k in [k for k in g.files if k.startswith("gcs:")]:
         # floor: the attention gamma gradient is a heavily cancelling sum (|g| ~ 2e-4 from terms ~1e-2)
         assert_checksums(params[k[4:]].grad, g[k], rel=1e-2, what=f"{variant} {k}", floor=4e-5)
+    # element-wise against the reference's own gradients (every 97th element of all 52 tensors); the kinked variants
+    # (ReLU / LeakyReLU, esp. with attention) move by a few percent when one pre-activation changes side of its kink -
+    # the oracle itself is 3.9e-2 from the reference there (tests/test_oracle_golden.py)
+    rel = {"plain": 1e-2, "gelu": 5e-3, "attn": 8e-2, "attn_gelu": 5e-3}[variant]
+    assert_grad_samples(lambda k: params[k].grad, g, "gs97:", rel=rel, what=f"{variant} vs reference", floor=4e-5 if "attn" in variant else 2e-7)
 
 
 def test_unet_mask_full_tensor_vs_oracle(cuda):
@@ -209,6 +221,7 @@ def test_unet_mask_three_frames_flow_warp_gpu(cuda):
     params = dict(model.named_parameters())
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=1e-2, what=f"n3 {k}", floor=1e-3)
+    assert_grad_samples(lambda k: params[k].grad, g, "gs397:", rel=5e-3, what="n3 vs reference", floor=1e-6)
 
 
 def test_attention_head_dim_not_multiple_of_4(cuda):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, golden_state, load_golden, oracle,
+from helpers import (UNET_VARIANTS, WARP_HP, assert_checksums, assert_close, assert_grad_samples, golden_state, load_golden, oracle,
                      strided, synthetic_cpu_batch, unet_hp)
 from oracle.procedural import procedural_state_dict
 
@@ -124,8 +124,8 @@ def test_warp_model_training_step():
     out = oracle.warp_losses(params, batch, WARP_HP, consts, bn)
     assert_close(out["theta"], g["theta"], atol=1e-5, what="theta")
     assert_close(strided(out["grid"].permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")  # end-to-end: theta error x TPS gain
-    # white-noise cloth: d(sample)/d(grid) ~ 2 * W/2 per unit grid, so the 1e-5 grid tolerance maps to ~3e-3 here
-    assert_close(strided(out["warped_cloth"]), g["warped_cloth_s8"], atol=5e-3, what="warped cloth")
+    # band-limited cloth: bilinear sampling turns the <= 1e-5 grid difference into <= 1e-4 here (measured 7.7e-5)
+    assert_close(strided(out["warped_cloth"]), g["warped_cloth_s8"], atol=2e-4, what="warped cloth")
     assert abs(out["loss/G"].item() - float(g["loss"])) < 1e-5
     out["loss/G"].backward()
     # the L1 sign() and the bilinear taps make the loss piecewise: a few samples switch piece under a 1e-5 grid change
@@ -134,6 +134,9 @@ def test_warp_model_training_step():
     assert_close(params["regression.linear.bias"].grad, g["grad_linear_bias"], atol=2e-3 * float(np.abs(g["grad_linear_bias"]).max()), what="d linear.bias")
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=2e-3, what=k)
+    # every 97th element of EVERY gradient against the reference's own backward pass (worst: the person-branch extractor,
+    # whose fp32 gradients are ill-conditioned - tests/test_parity_bs4_gpu.py prints their distance from fp64)
+    assert assert_grad_samples(lambda k: params[k].grad, g, "gs97:", rel=6e-3, what="warp") == 62
     assert_close(bn["extractionA.model.2.running_mean"], g["bn_rm_A2"], atol=1e-6, what="BN running mean")
     assert_close(bn["extractionA.model.2.running_var"], g["bn_rv_A2"], atol=1e-6, what="BN running var")
     assert_close(bn["regression.conv.10.running_mean"], g["bn_rm_R10"], atol=1e-5, what="BN running mean R10")
@@ -155,6 +158,11 @@ def test_unet_mask_training_step(variant):
     out["loss/G"].backward()
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=f"{variant} {k}")
+    # element-wise (every 97th element of every gradient).  "attn" = ReLU / LeakyReLU kinks + attention: the oracle's einsum
+    # and the reference's bmm round differently, a handful of pre-activations change side of a kink (measured 3.9e-2 on one
+    # scalar, <= 3.2e-2 on tensors); the smooth-activation variants agree to 1.5e-3.
+    n = assert_grad_samples(lambda k: params[k].grad, g, "gs97:", rel=5e-2 if variant == "attn" else 3e-3, what=variant)
+    assert n == len([k for k in params if params[k].requires_grad])
 
 
 def test_png_quantisation_truncates():
@@ -185,6 +193,7 @@ def test_unet_mask_three_frames_flow_warp():
     out["loss/G"].backward()
     for k in [k for k in g.files if k.startswith("gcs:")]:
         assert_checksums(params[k[4:]].grad, g[k], rel=5e-3, what=f"n3 {k}", floor=1e-3)
+    assert_grad_samples(lambda k: params[k].grad, g, "gs397:", rel=3e-3, what="n3 flow_warp", floor=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------ dataset-side prep (f3)
@@ -277,6 +286,17 @@ def test_sams_oracle_three_steps_match_the_reference(tag):
             # the reference's own fp32 round-off (its distance from the fp64 value) bounds what can be asked of the oracle
             tol = 5e-3 * ref[1] + 10 * abs(ref[1] - exact[1])
             assert abs(got[1] - ref[1]) <= tol, (tag, idx, k, got, ref, exact)
+        # element-wise: every 97th element of EVERY gradient of the step against the reference's own backward pass
+        for k in names:
+            ref = g[f"gs{idx}:{k}"].astype(np.float64)
+            got = grads[k].contiguous().reshape(-1)[::97].double().numpy()
+            exact = steps64[idx][1][k].contiguous().reshape(-1)[::97].numpy()
+            if _cs(steps64[idx][1][k])[1] <= 1e-6 * max(g[f"gcs{idx}:{k}"][1], _cs(grads[k])[1]):
+                continue  # analytically zero: handled by the checksum rule above
+            # 1e-2 of the tensor's max (ReLU kinks: one pre-activation on the other side moves an element by ~6e-3 of max
+            # between two fp32 evaluations) + the reference's own distance from the fp64 value
+            tol = 1e-2 * float(steps64[idx][1][k].abs().max()) + 10 * np.abs(ref - exact).max()
+            assert np.abs(got - ref).max() <= tol, (tag, idx, k, np.abs(got - ref).max(), tol)
         for k in g.files:
             if k.startswith(f"grad{idx}:"):
                 ref = g[k]

@@ -209,15 +209,17 @@ def test_unet_mask_model_bs4_all_outputs_and_every_gradient(cuda):
     assert n == 52  # 52 U-Net tensors (VGG frozen)
 
 
-def test_chained_step_bs4_through_the_timed_schedule(cuda):
-    """bench.py's step: graphs.GraphedChainedStep (three hipGraphs, two streams) at bs=4.  One replay, then every
+@pytest.mark.parametrize("bs", [4, 8])
+def test_chained_step_through_the_timed_schedule(cuda, bs):
+    """bench.py's step: graphs.GraphedChainedStep (three hipGraphs, two streams) at bs=4 (BASELINE's headline batch) and at
+    bs=8 (BASELINE config 4's per-GPU batch, the reference default options/base_options.py:32).  One replay, then every
     gradient of both models against the oracle; the try-on stage's oracle is fed the warped cloth the GPU produced (the
     reference's hand-off passes the warp stage's OUTPUT on, models/warp_model.py:143-149 -> datasets/vvt_dataset.py:139-150)."""
     from shineon_virtual_tryon_amd.graphs import GraphedChainedStep
     from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
     from shineon_virtual_tryon_amd.warp_model import WarpModel
 
-    batch_cpu = _smooth_batch()
+    batch_cpu = _smooth_batch(bs)
     batch = _to(batch_cpu, cuda)
     warp, wsd = _build(WarpModel, cuda, person_inputs=["agnostic", "cocopose"])
     unet, usd = _build(UnetMaskModel, cuda, self_attn=True, activation="gelu")
@@ -235,7 +237,7 @@ def test_chained_step_bs4_through_the_timed_schedule(cuda):
     w64, _ = oracle_warp(wsd, batch_cpu, torch.float64)
     assert abs(float(g.result_warp.minimize) - float(wref["loss/G"])) <= 2e-5
     assert_close(g.warped, wref["warped_cloth"], atol=1e-4, what="chained: warped cloth")
-    compare_all_gradients(warp, w32, w64, "chained/warp bs=4 (graph replay)")
+    compare_all_gradients(warp, w32, w64, f"chained/warp bs={bs} (graph replay)")
 
     b2 = dict(batch_cpu)
     b2["cloth"] = g.cloth_tryon.detach().cpu().contiguous()
@@ -245,7 +247,7 @@ def test_chained_step_bs4_through_the_timed_schedule(cuda):
         r = float(uref[k])
         assert abs(float(g.result_tryon.logs[k]) - r) <= 2e-5 + 2e-5 * abs(r), (k, float(g.result_tryon.logs[k]), r)
     assert_close(unet.p_tryons[0], uref["p_tryons"], atol=1e-4, what="chained: p_tryon")
-    compare_all_gradients(unet, u32, u64, "chained/try-on bs=4 (graph replay)")
+    compare_all_gradients(unet, u32, u64, f"chained/try-on bs={bs} (graph replay)")
 
 
 def test_committed_igemm_plans_are_the_ones_in_use(cuda):

@@ -22,6 +22,11 @@ def _ops():
     return ops, ops_sams
 
 
+def ops_to_oihw(t):
+    """A parameter gradient in the logical (O, I, R, S) element order (the memory is OHWI)."""
+    return t.detach().contiguous()
+
+
 def _nchw(t):
     ops, _ = _ops()
     return ops.to_nchw(t).cpu()
@@ -371,6 +376,20 @@ def test_sams_three_training_steps_match_the_oracle(tag):
                 kinks = found
         else:
             _compare_grads(got, ref32[idx][1], ref64[idx][1], f"{tag} step {idx}", kink=kinks[idx])
+        # element-wise against the REFERENCE's own backward pass (golden: every 97th element of every gradient): wherever two
+        # fp32 CPU evaluations (the reference, the oracle) agree to 2e-3 of the tensor's max - i.e. the tensor is neither
+        # ill-conditioned nor next to a ReLU kink - the HIP gradient is within 1e-2 of the reference's
+        checked = 0
+        for k, gr in got.items():
+            ref = g[f"gs{idx}:{k}"].astype(np.float64)
+            o32 = ref32[idx][1][k].contiguous().reshape(-1)[::97].double().numpy()
+            big = max(np.abs(ref).max(), 1e-30)
+            if ref64[idx][1][k].abs().max().item() <= 1e-6 * big or np.abs(o32 - ref).max() > 2e-3 * big:
+                continue
+            mine = ops_to_oihw(gr).reshape(-1)[::97].double().cpu().numpy()
+            assert np.abs(mine - ref).max() <= 1e-2 * big, (tag, idx, k, np.abs(mine - ref).max(), big)
+            checked += 1
+        assert checked >= 0.8 * len(got), (tag, idx, checked, len(got))
         if idx == 0:
             fr = model.all_gen_frames.cpu()
             big = frames64.abs().max().item()
@@ -577,3 +596,115 @@ def test_sams_full_size_properties():
             w = m.weight_orig.detach().reshape(m.weight_orig.shape[0], -1)
             sigma = torch.dot(m.weight_u, torch.mv(w, m.weight_v))
             assert float(sigma) > 0, name
+
+
+def _host_free_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_sams_full_size_three_training_steps_match_the_oracle():
+    """the configuration bench.py --config sams times (reference-default networks: generator 64..1024 features,
+    184.8 M parameters; 256x192; n_frames_total = 5; flow_warp) at bs = 1, against the oracle on the box's host cores in fp32
+    AND fp64: the generator step and both discriminator steps - every logged scalar, all five generated frames, and every
+    gradient of each step's parameter set element-wise under the rule of the small-size tests.
+    models/sams_model.py:147-383 with options/gan_options.py defaults."""
+    import bench
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.sams_model import SamsModel
+    from shineon_virtual_tryon_amd.trainer import MultiOptimizerStep
+    from oracle.procedural import shapes_of
+
+    if _host_free_gib() < 40:
+        pytest.skip("the fp64 oracle of the full-size SAMS step needs ~40 GiB of host memory")
+    hp = bench.sams_hparams()
+    model = SamsModel(hp)
+    sd = procedural_state_dict(shapes_of(model.state_dict()))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()
+    assert abs(sum(p.numel() for p in model.generator.parameters()) / 1e6 - 184.8) < 0.1
+    batch = synthetic_batch(1, "cpu", n_frames=hp.n_frames_total, smooth=True)
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    ref32, frames32, _ = sh.oracle_three_steps(sd, hp, batch)
+    ref64, frames64, _ = sh.oracle_three_steps(sd, hp, batch, torch.float64)
+    dbatch = _to(batch, DEV)
+    nets = model.optimizer_networks()
+    stepper = MultiOptimizerStep.__new__(MultiOptimizerStep)
+    stepper._all = list(model.parameters())
+    stepper._own = [list(n.parameters()) for n in nets]
+    kinks = None
+    for idx, name in enumerate(sh.STEP_NETS):
+        stepper._only(idx)
+        model.zero_grad(set_to_none=True)
+        res = model.training_step(dbatch, 0, idx)
+        res.minimize.sum().backward()
+        for k, v in res.logs.items():
+            r32, r64 = ref32[idx][0][k], ref64[idx][0][k]
+            assert min(abs(float(v) - r32), abs(float(v) - r64)) <= 2e-4 * max(1.0, abs(r64)), (idx, k, float(v), r32, r64)
+        got = {f"{name}.{k}": p.grad for k, p in nets[idx].named_parameters() if p.grad is not None}
+        print(f"[sams full size] step {idx} ({name}): {len(got)} gradient tensors, logs "
+              + ", ".join(f"{k}={float(v):.5f}" for k, v in res.logs.items()))
+        if kinks is None:
+            found = _compare_grads(got, ref32[idx][1], ref64[idx][1], f"full-size step {idx}",
+                                   kink=lambda: sh.kink_spread(sd, hp, batch, ref64))
+            if isinstance(found, list):
+                kinks = found
+        else:
+            _compare_grads(got, ref32[idx][1], ref64[idx][1], f"full-size step {idx}", kink=kinks[idx])
+        if idx == 0:
+            fr = model.all_gen_frames.cpu()
+            big = frames64.abs().max().item()
+            e32, e64 = (fr - frames32).abs().max().item(), (fr.double() - frames64).abs().max().item()
+            print(f"[sams full size] generated frames: max|ours - fp32 oracle| {e32:.2e}, |ours - fp64| {e64:.2e}, "
+                  f"|fp32 oracle - fp64| {(frames32.double() - frames64).abs().max().item():.2e} (max {big:.2f})")
+            assert min(e32, e64) <= 1e-4 * max(big, 1.0), ("frames", e32, e64, big)
+
+
+def test_sams_full_size_generator_pass_bs4_vs_oracle():
+    """The reference-default generator at the batch bench.py times (bs = 4, 256x192, four previous frames): one forward +
+    backward pass against oracle.generator_forward in fp32 and fp64 - output and every parameter gradient.  These are the
+    bs = 4 layer shapes (igemm instantiations / split-K plans from the committed plans file) of the timed step."""
+    import bench
+    from oracle.procedural import shapes_of
+    from shineon_virtual_tryon_amd.networks.sams.sams_generator import SamsGenerator
+
+    if _host_free_gib() < 40:
+        pytest.skip("needs ~40 GiB of host memory for the fp64 oracle")
+    hp = bench.sams_hparams()
+    gen = SamsGenerator(hp)
+    sd = procedural_state_dict({"generator." + k: v for k, v in shapes_of(gen.state_dict()).items()})
+    gen.load_state_dict({k[len("generator."):]: v for k, v in sd.items()})
+    gen = gen.to(DEV).train()
+    torch.manual_seed(12)
+    b, n, h, w = 4, hp.n_frames_total, hp.fine_height, hp.fine_width
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+
+    batch = synthetic_batch(b, "cpu", n_frames=n, smooth=True)
+    prev_frames = batch["image"][:, :n - 1].contiguous()
+    prev_maps = batch["flow"][:, :n - 1].contiguous()
+    maps = {k: batch[k][:, -1].contiguous() for k in ("agnostic", "densepose", "flow", "cloth")}
+    gout = torch.randn(b, 4, h, w) / (h * w)
+    refs = []
+    for dtype in (torch.float32, torch.float64):
+        osd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in osd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+                v.requires_grad_(True)
+        out = so.generator_forward(osd, prev_frames.to(dtype), prev_maps.to(dtype), {k: v.to(dtype) for k, v in maps.items()}, hp, True)
+        out.backward(gout.to(dtype))
+        refs.append((out.detach(), {k[len("generator."):]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}))
+        del osd
+    y = gen(prev_frames.to(DEV), prev_maps.to(DEV), {k: v.to(DEV) for k, v in maps.items()})
+    y.backward(gout.to(DEV))
+    (o32, g32), (o64, g64) = refs
+    got = _nchw(y).double()
+    e32, e64 = (got - o32.double()).abs().max().item(), (got - o64).abs().max().item()
+    print(f"[sams generator bs=4] output: |ours - fp32 oracle| {e32:.2e}, |ours - fp64| {e64:.2e}, |fp32 oracle - fp64| "
+          f"{(o32.double() - o64).abs().max().item():.2e}, max {o64.abs().max().item():.3f}")
+    assert min(e32, e64) <= 1e-4 * max(1.0, o64.abs().max().item())
+    _compare_grads({k: p.grad for k, p in gen.named_parameters() if p.grad is not None}, g32, g64, "generator bs=4 full size")
