@@ -77,6 +77,29 @@ int so_conv2d_wgrad_acc(const float* dy, int lddy, const float* x, int ldx, floa
                         int W, int C, int Ko, int R, int S, int stride, int pad, float* ws,
                         long long ws_bytes, void* stream);
 
+/* ---- Winograd F(2x2, 3x3) for 3x3 / stride 1 / padding 1 convolutions (csrc/wino.hip) -------------------------------
+ * Replaces torch conv2d at models/networks/vgg.py:9-23 (frozen VGG19 chain of the perceptual loss, loss.py:106-122) and its
+ * autograd input gradient: 16 multiplications per 2x2 output tile and channel pair instead of 36, all in fp32.
+ * so_wino_weights: U[16][Ko][C] = G g G^T from OHWI weights w[Kw][3][3][C] (rows >= Kw zero); flip_transpose = 1 builds
+ *   U'[16][C][Ko] from the flipped taps - the input gradient is then the same convolution with C and Ko swapped.
+ * so_wino_conv3x3: y = gate(act(conv(x) + bias)); x [Nb*H*W][C] (ldx), y [Nb*H*W][Ko] (ldy), C % 4 == Ko % 4 == 0;
+ *   `gate` (optional, pitch ldy): y = gate > 0 ? y : 0 (ReLU backward fused, as so_conv2d_dgrad_t_gated);
+ *   wino_ws: so_wino_ws_floats(...) floats (V[16][tiles][C] and M[16][tiles][Ko]); ws: split-K scratch of the GEMM. */
+long long so_wino_ws_floats(int Nb, int H, int W, int C, int Ko);
+int so_wino_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream);
+int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                    int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, float* wino_ws,
+                    long long wino_ws_bytes, float* ws, long long ws_bytes, void* stream);
+
+/* Fused form: input transform, the 16 GEMMs and the output transform in ONE launch (transformed operands never touch HBM).
+ * Weights in the kernel's own order U[ceil(K/8)][16][N][8] with (N, K) = (Ko, C) (flip_transpose = 0) or (C, Ko) built from
+ * the flipped taps (flip_transpose = 1: the input gradient, called with x = dy, C <- Ko, Ko <- C).  Same reference call
+ * sites and argument meaning as so_wino_conv3x3; no workspace. */
+long long so_wino_fused_weight_floats(int Ko, int C, int flip_transpose);
+int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream);
+int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                          int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream);
+
 /* torch.bmm replacement (sagan.py:44,50; warp.py:63):
  * C[b] = act(alpha[0] * opA(A[b]) opB(B[b]) + bias[n] + res[b]),  alpha/bias/res optional (NULL).
  * transa 0: A [M][K]; 1: A [K][M].  transb 0: B [K][N]; 1: B [N][K].  (transa=1,transb=1 unsupported) */
@@ -317,18 +340,6 @@ int so_threshold_mask(const float* x, int C, float threshold, float* mask, int N
 /* get_person_flow (tryon_dataset.py:272-298): .flo payload [Nb][HW][2] (u, v interleaved) -> planar [Nb][2][HW]
  * followed by transforms.Normalize((0.5, 0.5), (0.5, 0.5)). */
 int so_flow_decode(const float* payload, float* flow, int Nb, int HW, void* stream);
-
-/* ---- SAGAN self-attention core, LDS-resident (csrc/attention.hip; sagan.py:44-54) ------------------------------ */
-/* qkv [B*N][E = 2d + C]: columns [0,d) = query, [d,2d) = key, [2d,E) = value projections of x (one engine GEMM).
- * fwd: attn [B*N][N] = softmax_j(q k^T) (saved for backward), o [B*N][C] = attn v (saved), out = gamma * o + x.
- * bwd: de [B*N][N] (scratch), dqkv [B*N][E] <- (dq | dk | dv) with dv = gamma * attn^T dout, da = gamma * dout v^T.
- * Supported when so_attention_supported(N, C, d): N <= 192, C in {128, 256, 384, 512}, d in {32, 64}; otherwise SO_ERR_SHAPE
- * (the host then uses the GEMM + softmax composition). */
-int so_attention_supported(int N, int C, int d);
-int so_attention_fwd(const float* qkv, int E, int d, const float* x, int ldx, const float* gamma, float* out, int ldo,
-                     float* attn, float* o, int B, int N, int C, void* stream);
-int so_attention_bwd(const float* qkv, int E, int d, const float* dout, int ldg, const float* attn, const float* gamma,
-                     float* de, float* dqkv, int B, int N, int C, void* stream);
 
 /* ---- split-bf16 3x3 convolution for the frozen VGG19 chain (csrc/sb16.hip; opt-in, non-headline) ----------------- */
 /* fp32 = hi + mid (two bf16 planes); a*b ~= hi*hi + hi*mid + mid*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation

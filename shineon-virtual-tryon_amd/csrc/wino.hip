@@ -1,0 +1,552 @@
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / padding 1 convolutions of the try-on hot path (fp32 throughout).
+//
+// Reference ops replaced: torch conv2d at models/networks/vgg.py:9-23 (the frozen VGG19 chain of the perceptual loss,
+// models/networks/loss.py:106-122: 57 % of the step's FLOPs) and its input gradient (autograd).
+//
+// On CDNA4 the fp32-input MFMA runs at the VECTOR rate (157 TFLOP/s), so the only way past the direct convolution's
+// roofline in exact-type fp32 arithmetic is to multiply less: F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input
+// tile with 16 multiplications per (input channel, output channel) instead of 36 - 2.25x fewer MFMA FLOPs.  All
+// transform coefficients are 0, +-1, +-1/2, so the arithmetic stays fp32 with round-off of the same order as the
+// direct sum (measured by tests/test_ops_gpu.py against the fp64 convolution).
+//
+//   V[xi][tile][c]  = (B^T d B)[xi]      input transform   (HBM-bound: reads x once, writes 4x its size)
+//   M[xi][tile][ko] = sum_c V[xi][tile][c] * U[xi][ko][c]   16 independent GEMMs = ONE batched launch of the fp32
+//                                                           MFMA engine (igemm2.hip, batch = 16)
+//   y[2x2 of tile]  = A^T M A + bias -> activation -> ReLU gate    output transform (HBM-bound)
+//   U[xi][ko][c]    = (G g G^T)[xi]      weight transform (once for frozen weights)
+//
+// The input gradient of such a convolution is the same convolution with flipped taps and the channel roles swapped:
+// U'[xi][c][ko] = G flip(g) G^T, so one code path serves forward and backward.
+//
+// This non-fused form pays 16/4 = 4x the activation size in V and in M (write + read each); it wins where the GEMM
+// dominates that traffic (C, Ko >= 128).  See DESIGN.md 3.7 for the measured crossover.
+#include "common.h"
+#include "../../include/shineon_hip.h"
+
+extern "C" int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A, int lda, long long sa,
+                               const float* B, int ldb, long long sb, float* C, int ldc, long long sc, int batch,
+                               const float* alpha, const float* bias, const float* res, int ldres, long long sres, int act,
+                               float act_param, float* ws, long long ws_bytes, void* stream);
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// one thread = (tile, channel quad): 16 16-byte loads, 32 vector adds, 16 16-byte stores
+__global__ __launch_bounds__(256) void wino_input_k(const float* __restrict__ x, int ldx, float* __restrict__ V, int Nb, int H,
+                                                    int W, int C, int th, int tw) {
+  const int cq = C >> 2;
+  const long long total = (long long)Nb * th * tw * cq;
+  const long long T = (long long)Nb * th * tw;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long tile = idx / cq;
+    const int c = (int)(idx - tile * cq) * 4;
+    const int n = (int)(tile / (th * tw));
+    const int rem = (int)(tile - (long long)n * th * tw);
+    const int ty = rem / tw, tx = rem - ty * tw;
+    const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = h0 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = w0 + j;
+        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        d[i][j] = ok ? ld4(x + ((long long)(n * H + h) * W + w) * ldx + c) : z;
+      }
+    }
+    // B^T d : combine rows
+    f32x4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0][j] - d[2][j];
+      t[1][j] = d[1][j] + d[2][j];
+      t[2][j] = d[2][j] - d[1][j];
+      t[3][j] = d[1][j] - d[3][j];
+    }
+    // (B^T d) B : combine columns
+    float* out = V + tile * C + c;
+    const long long sx = T * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<f32x4*>(out + (i * 4 + 0) * sx) = t[i][0] - t[i][2];
+      *reinterpret_cast<f32x4*>(out + (i * 4 + 1) * sx) = t[i][1] + t[i][2];
+      *reinterpret_cast<f32x4*>(out + (i * 4 + 2) * sx) = t[i][2] - t[i][1];
+      *reinterpret_cast<f32x4*>(out + (i * 4 + 3) * sx) = t[i][1] - t[i][3];
+    }
+  }
+}
+
+// one thread = (tile, output-channel quad): 16 loads, A^T M A, bias / activation / gate, four 16-byte pixel stores
+__global__ __launch_bounds__(256) void wino_output_k(const float* __restrict__ Mx, const float* __restrict__ bias, int nbias,
+                                                     const float* __restrict__ gate, float* __restrict__ y, int ldy, int Nb,
+                                                     int H, int W, int Ko, int th, int tw, int act, float act_param) {
+  const int kq = Ko >> 2;
+  const long long T = (long long)Nb * th * tw;
+  const long long total = T * kq;
+  const long long sx = T * Ko;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long tile = idx / kq;
+    const int k = (int)(idx - tile * kq) * 4;
+    const int n = (int)(tile / (th * tw));
+    const int rem = (int)(tile - (long long)n * th * tw);
+    const int ty = rem / tw, tx = rem - ty * tw;
+    const float* src = Mx + tile * Ko + k;
+    f32x4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[i][j] = ld4(src + (i * 4 + j) * sx);
+    f32x4 s[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[0][j] = m[0][j] + m[1][j] + m[2][j];
+      s[1][j] = m[1][j] - m[2][j] - m[3][j];
+    }
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = (k + q < nbias) ? bias[k + q] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int h = 2 * ty + a;
+      if (h >= H) continue;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int w = 2 * tx + bb;
+        if (w >= W) continue;
+        f32x4 v = (bb == 0 ? s[a][0] + s[a][1] + s[a][2] : s[a][1] - s[a][2] - s[a][3]) + b;
+        if (act != SO_ACT_NONE) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = so_actf(act, v[q], act_param);
+        }
+        const long long off = ((long long)(n * H + h) * W + w) * ldy + k;
+        if (gate) {
+          const f32x4 g = ld4(gate + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = g[q] > 0.f ? v[q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + off) = v;
+      }
+    }
+  }
+}
+
+// one thread = one (ko, c) filter: U = G g G^T
+__global__ __launch_bounds__(256) void wino_weights_k(const float* __restrict__ w, float* __restrict__ U, int Ko, int C,
+                                                      int Kw, int flip_transpose) {
+  const long long total = (long long)Ko * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int ko = (int)(idx / C), c = (int)(idx - (long long)ko * C);
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int rr = flip_transpose ? 2 - r : r, ss = flip_transpose ? 2 - s : s;
+        g[r][s] = ko < Kw ? w[((long long)ko * 9 + rr * 3 + ss) * C + c] : 0.f;
+      }
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      t[0][s] = g[0][s];
+      t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+      t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+      t[3][s] = g[2][s];
+    }
+    const long long sx = (long long)Ko * C;
+    float* out = flip_transpose ? U + (long long)c * Ko + ko : U + (long long)ko * C + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out[(i * 4 + 0) * sx] = t[i][0];
+      out[(i * 4 + 1) * sx] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      out[(i * 4 + 2) * sx] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      out[(i * 4 + 3) * sx] = t[i][2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// FUSED F(2x2, 3x3): input transform, the 16 GEMMs and the output transform in ONE kernel - V and M never exist in HBM.
+//
+// Block = 512 threads (8 waves, 2 per SIMD), one per CU (87 KB LDS): a patch of 8 x 4 Winograd tiles (16 x 8 output pixels of
+// one image, 18 x 10 input pixels) x KB = 64 output channels x all 16 transform points.  Wave w owns transformed ROW
+// i = w & 3 (points xi = 4 i + j, j = 0..3) of output-channel group kg = w >> 2 (32 channels): four independent 32 x 32
+// accumulators, the MFMA M axis = the 32 tiles, N axis = output channels, K axis = input channels.
+// K loop, 8 input channels per step, double-buffered LDS, prefetch distance 2 (as in igemm2.hip):
+//   * A stage: the RAW 18 x 10 input patch, 8 channels per pixel (straight 16-byte copies; image borders / padding are
+//     out-of-range buffer loads = 0).  The input transform happens when a wave builds its fragments ("transform at read"):
+//     row i of B^T d B needs two patch rows (a1, a2) and all four patch columns - 8 ds_read_b128 and 8 vector adds yield the
+//     four A fragments (one per j) for a lane's tile; each transformed value is consumed by exactly one wave pair, so
+//     nothing is computed twice.  Even / odd patch rows and columns are stored in separate halves (slot = x>>1 + (x&1)*9)
+//     with a 12-float pixel pitch and 24 slots per row: the stride-2 tile walk of the 16 lanes of a ds_read_b128 group then
+//     hits 16 distinct bank quads (derivation in DESIGN.md 3.7).
+//   * B stage: U[c/8][xi][ko][8] (so_wino_weights layout 2): the block's slice of one step is 16 contiguous 2 KB runs.
+// Epilogue: A^T M A = column combination in registers (over the wave's four j accumulators), row combination through
+// LDS (8 planes of 32 x 64 floats), then bias / activation / ReLU gate and 16-byte pixel stores (256 B per pixel).
+struct WinoP {
+  const float* x;
+  const float* U;
+  const float* bias;
+  const float* gate;
+  float* y;
+  unsigned x_bytes, u_bytes;
+  int ldx, ldy, Nb, H, W, C, Ko, nbias, pbx, pby, nkb, nks, act;
+  float act_param;
+};
+
+#define WF_SB() __builtin_amdgcn_sched_barrier(0x006)
+#define WF_OOB 0x80000000u
+typedef int wf_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 wf_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  const wf_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+  f32x4 r;
+  r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]); r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
+  return r;
+}
+
+constexpr int WF_KB = 64;                  // output channels per block
+constexpr int WF_APIX = 12;                // floats per pixel slot in the raw A stage (8 data + 4 pad)
+constexpr int WF_AROW = 24;                // pixel slots per patch row
+constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 2880 floats = 11.25 KB
+constexpr int WF_BSTAGE = 16 * WF_KB * 8;           // 8192 floats = 32 KB
+constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 88.5 KB; the epilogue re-uses the first 64 KB
+
+__global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * WF_ASTAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wi = wave & 3, kg = wave >> 2;
+
+  // XCD-aware block -> (patch, ko block) map: XCD x works on the x-th contiguous eighth of the (patch, kb) order, so the
+  // ko blocks of one patch (which re-read the same input pixels) and neighbouring patches (halo) share one L2
+  const unsigned tot = gridDim.x, lin = blockIdx.x;
+  const unsigned xper = tot >> 3, xrem = tot & 7, xcd = lin & 7;
+  const unsigned lg = xcd * xper + (xcd < xrem ? xcd : xrem) + (lin >> 3);
+  const int kb = (int)(lg % (unsigned)p.nkb);
+  const int patch = (int)(lg / (unsigned)p.nkb);
+  const int pxb = patch % p.pbx;
+  const int t2 = patch / p.pbx;
+  const int pyb = t2 % p.pby;
+  const int n = t2 / p.pby;
+  const int k0 = kb * WF_KB;
+  const int h_org = 8 * pyb - 1, w_org = 16 * pxb - 1;   // input pixel of patch position (0, 0)
+
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, (int)p.u_bytes, 0x00020000);
+
+  // ---- loader state ------------------------------------------------------------------------------------------------
+  // A: threads 0..359 copy (pixel = tid >> 1, channel quad = tid & 1) of the 18 x 10 patch
+  int a_src = -1, a_dst = 0;
+  const int aq = tid & 1;
+  if (tid < 360) {
+    const int pix = tid >> 1;
+    const int ppy = pix / 18, ppx = pix - ppy * 18;
+    const int h = h_org + ppy, w = w_org + ppx;
+    if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) a_src = ((n * p.H + h) * p.W + w) * p.ldx + aq * 4;
+    const int rs = (ppy >> 1) + (ppy & 1) * 5, cs = (ppx >> 1) + (ppx & 1) * 9;
+    a_dst = (rs * WF_AROW + cs) * WF_APIX + aq * 4;
+  }
+  // B: 2048 quads per step = 4 per thread: quad id = tid + 512 m -> row = xi * 64 + ko_local, quad = id & 1
+  int b_src[4], b_dst[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int qid = tid + 512 * m;
+    const int row = qid >> 1, q = qid & 1;
+    const int xi = row >> 6, kol = row & 63;
+    b_src[m] = (k0 + kol < p.Ko) ? (xi * p.Ko + k0 + kol) * 8 + q * 4 : -1;
+    b_dst[m] = row * 8 + ((q ^ ((row >> 3) & 1)) << 2);
+  }
+  const int b_step = 16 * p.Ko * 8;   // floats per K step in U
+
+  auto load_a = [&](int s) -> f32x4 {
+    const int c = 8 * s + aq * 4;
+    const bool ok = (a_src >= 0) & (c < p.C);
+    return wf_bload(rX, ok ? (unsigned)(a_src + 8 * s) * 4u : WF_OOB);
+  };
+  auto load_b = [&](int s, f32x4 (&dst)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const bool ok = (b_src[m] >= 0) & (s < p.nks);
+      dst[m] = wf_bload(rU, ok ? (unsigned)(b_src[m] + s * b_step) * 4u : WF_OOB);
+    }
+  };
+  auto store_a = [&](int st, const f32x4& v) {
+    if (tid < 360) *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst) = v;
+  };
+  auto store_b = [&](int st, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(Bs + st * WF_BSTAGE + b_dst[m]) = v[m];
+  };
+
+  // ---- fragment addresses (K-step invariant) -------------------------------------------------------------------------
+  // transformed row i = wi:  t[b] = d[a1][b] + sgn * d[a2][b]   (B^T rows: (1,0,-1,0) (0,1,1,0) (0,-1,1,0) (0,1,0,-1))
+  const int a1 = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
+  const int a2 = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+  const float sgn = wi == 1 ? 1.f : -1.f;
+  const int ttx = li & 7, tty = li >> 3;
+  int fa1[4], fa2[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int cs = ttx + (b >> 1) + (b & 1) * 9;
+    fa1[b] = ((tty + (a1 >> 1) + (a1 & 1) * 5) * WF_AROW + cs) * WF_APIX + lh * 4;
+    fa2[b] = ((tty + (a2 >> 1) + (a2 & 1) * 5) * WF_AROW + cs) * WF_APIX + lh * 4;
+  }
+  int fb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (4 * wi + j) * 64 + kg * 32 + li;
+    fb[j] = row * 8 + ((lh ^ ((row >> 3) & 1)) << 2);
+  }
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  f32x4 ra, rb[4];
+  {
+    f32x4 ra0, rb0[4];
+    ra0 = load_a(0);
+    load_b(0, rb0);
+    ra = load_a(1);
+    load_b(1, rb);
+    store_a(0, ra0);
+    store_b(0, rb0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int s = 0; s < p.nks; ++s) {
+    const float* as = As + cur * WF_ASTAGE;
+    const float* bs = Bs + cur * WF_BSTAGE;
+    f32x4 d1[4], d2[4], bf[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      d1[b] = *reinterpret_cast<const f32x4*>(as + fa1[b]);
+      d2[b] = *reinterpret_cast<const f32x4*>(as + fa2[b]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + fb[j]);
+    WF_SB();
+    f32x4 t[4], v[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[b][e] = __builtin_fmaf(sgn, d2[b][e], d1[b][e]);
+    v[0] = t[0] - t[2];
+    v[1] = t[1] + t[2];
+    v[2] = t[2] - t[1];
+    v[3] = t[1] - t[3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
+    WF_SB();
+    store_a(cur ^ 1, ra);
+    store_b(cur ^ 1, rb);
+    WF_SB();
+#pragma unroll
+    for (int e = 2; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
+    WF_SB();
+    ra = load_a(s + 2);
+    load_b(s + 2, rb);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------
+  // columns (in registers): P[i][0] = M[i][0] + M[i][1] + M[i][2],  P[i][1] = M[i][1] - M[i][2] - M[i][3]
+  float* Ps = smem;   // [i 4][b 2][tile 32][ko 64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
+    const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
+    Ps[((wi * 2 + 0) * 32 + tile) * 64 + kg * 32 + li] = p0;
+    Ps[((wi * 2 + 1) * 32 + tile) * 64 + kg * 32 + li] = p1;
+  }
+  __syncthreads();
+  // rows (through LDS): y[0][b] = P[0][b] + P[1][b] + P[2][b],  y[1][b] = P[1][b] - P[2][b] - P[3][b]
+  {
+    const int tile = tid >> 4, kq = (tid & 15) * 4;
+    const int ty = 4 * pyb + (tile >> 3), tx = 8 * pxb + (tile & 7);
+    const int ko = k0 + kq;
+    if (ko < p.Ko) {
+      f32x4 P[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) P[i][b] = *reinterpret_cast<const f32x4*>(Ps + ((i * 2 + b) * 32 + tile) * 64 + kq);
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = (ko + q < p.nbias) ? p.bias[ko + q] : 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int h = 2 * ty + a;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int w = 2 * tx + b;
+          if (h < p.H && w < p.W) {
+            f32x4 v = (a == 0 ? P[0][b] + P[1][b] + P[2][b] : P[1][b] - P[2][b] - P[3][b]) + bv;
+            if (p.act != SO_ACT_NONE) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = so_actf(p.act, v[q], p.act_param);
+            }
+            const long long off = ((long long)(n * p.H + h) * p.W + w) * p.ldy + ko;
+            if (p.gate) {
+              const f32x4 g = ld4(p.gate + off);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = g[q] > 0.f ? v[q] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + off) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// weights in the fused kernel's order: U[c/8][xi][ko][8] (channels beyond C zero-filled up to a multiple of 8)
+__global__ __launch_bounds__(256) void wino_weights_fused_k(const float* __restrict__ w, float* __restrict__ U, int Ko, int C,
+                                                            int Kw, int flip_transpose) {
+  // flip_transpose = 0: GEMM (N, K) = (ko, c) of w[ko][tap][c];  1: (N, K) = (c, ko), taps flipped (input gradient)
+  const int Nn = flip_transpose ? C : Ko, Kk = flip_transpose ? Ko : C;
+  const int K8 = (Kk + 7) / 8 * 8;
+  const long long total = (long long)Nn * K8;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int nn = (int)(idx / K8), kk = (int)(idx - (long long)nn * K8);
+    const int ko = flip_transpose ? kk : nn, c = flip_transpose ? nn : kk;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int rr = flip_transpose ? 2 - r : r, ss = flip_transpose ? 2 - s : s;
+        g[r][s] = (ko < Kw && kk < Kk) ? w[((long long)ko * 9 + rr * 3 + ss) * C + c] : 0.f;
+      }
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      t[0][s] = g[0][s];
+      t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+      t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+      t[3][s] = g[2][s];
+    }
+    // element (step = kk / 8, xi, nn, kk % 8)
+    float* out = U + ((long long)(kk >> 3) * 16 * Nn + nn) * 8 + (kk & 7);
+    const long long sx = (long long)Nn * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      out[(i * 4 + 0) * sx] = t[i][0];
+      out[(i * 4 + 1) * sx] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      out[(i * 4 + 2) * sx] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      out[(i * 4 + 3) * sx] = t[i][2];
+    }
+  }
+}
+
+inline int grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+long long so_wino_ws_floats(int Nb, int H, int W, int C, int Ko) {
+  const long long T = (long long)Nb * ((H + 1) / 2) * ((W + 1) / 2);
+  return 16 * T * ((long long)C + Ko);
+}
+
+// Ko rows are written; rows >= Kw are zero (output-channel padding).  flip_transpose = 0: U[16][Ko][C] for the forward
+// convolution; 1: U'[16][C][Ko] built from the flipped taps, for the input gradient (which is then the same convolution with
+// the roles of C and Ko swapped).
+int so_wino_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream) {
+  if (Ko <= 0 || C <= 0 || Kw > Ko) return SO_ERR_SHAPE;
+  hipLaunchKernelGGL(wino_weights_k, dim3(grid_for((long long)Ko * C)), dim3(256), 0, (hipStream_t)stream, w, U, Ko, C, Kw,
+                     flip_transpose);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                    int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, float* wino_ws,
+                    long long wino_ws_bytes, float* ws, long long ws_bytes, void* stream) {
+  if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
+      (((uintptr_t)wino_ws) & 15) || (gate && (((uintptr_t)gate) & 15)))
+    return SO_ERR_ALIGN;
+  const int th = (H + 1) / 2, tw = (W + 1) / 2;
+  const long long T = (long long)Nb * th * tw;
+  if (T <= 0 || T >= (1 << 24) || so_wino_ws_floats(Nb, H, W, C, Ko) * 4 > wino_ws_bytes) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* V = wino_ws;
+  float* Mx = wino_ws + 16 * T * C;
+  hipLaunchKernelGGL(wino_input_k, dim3(grid_for(T * (C >> 2))), dim3(256), 0, st, x, ldx, V, Nb, H, W, C, th, tw);
+  int err = SO_LAUNCH_CHECK();
+  if (err) return err;
+  err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 16, nullptr, nullptr, nullptr,
+                        0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
+  if (err) return err;
+  hipLaunchKernelGGL(wino_output_k, dim3(grid_for(T * (Ko >> 2))), dim3(256), 0, st, (const float*)Mx, bias, nbias, gate, y, ldy,
+                     Nb, H, W, Ko, th, tw, act, act_param);
+  return SO_LAUNCH_CHECK();
+}
+
+// ---- fused kernel --------------------------------------------------------------------------------------------------------
+// floats of the fused-layout weights: [ceil(K/8)][16][N][8] with (N, K) = (Ko, C) forward, (C, Ko) for the input gradient
+long long so_wino_fused_weight_floats(int Ko, int C, int flip_transpose) {
+  const long long Nn = flip_transpose ? C : Ko, Kk = flip_transpose ? Ko : C;
+  return (Kk + 7) / 8 * 16 * Nn * 8;
+}
+
+int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream) {
+  if (Ko <= 0 || C <= 0 || Kw > Ko) return SO_ERR_SHAPE;
+  const long long total = so_wino_fused_weight_floats(Ko, C, flip_transpose) / 16;
+  hipLaunchKernelGGL(wino_weights_fused_k, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, U, Ko, C, Kw,
+                     flip_transpose);
+  return SO_LAUNCH_CHECK();
+}
+
+// y = gate(act(conv3x3_s1_p1(x) + bias)) in ONE launch; U from so_wino_fused_weights with (N, K) = (Ko, C) of THIS call
+// (for an input gradient call it with x = dy, C = the convolution's Ko, Ko = its C and the flip_transpose = 1 weights).
+int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                          int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream) {
+  if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
+      (gate && (((uintptr_t)gate) & 15)))
+    return SO_ERR_ALIGN;
+  const long long xb = (long long)Nb * H * W * ldx * 4, ub = so_wino_fused_weight_floats(Ko, C, 0) * 4;
+  if (xb <= 0 || xb >= 0x7FFFFFF0LL || ub >= 0x7FFFFFF0LL) return SO_ERR_SHAPE;
+  WinoP p = {};
+  p.x = x; p.U = U; p.bias = bias; p.gate = gate; p.y = y;
+  p.x_bytes = (unsigned)xb; p.u_bytes = (unsigned)ub;
+  p.ldx = ldx; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.C = C; p.Ko = Ko; p.nbias = nbias;
+  p.pbx = ((W + 1) / 2 + 7) / 8; p.pby = ((H + 1) / 2 + 3) / 4;
+  p.nkb = (Ko + WF_KB - 1) / WF_KB; p.nks = (C + 7) / 8;
+  p.act = act; p.act_param = act_param;
+  const long long blocks = (long long)Nb * p.pbx * p.pby * p.nkb;
+  if (blocks <= 0 || blocks > 0x7FFFFFFF) return SO_ERR_SHAPE;
+  constexpr size_t lds = (size_t)WF_LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino_fused_k, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p);
+  return SO_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -84,16 +84,17 @@ CONCURRENT_WGRAD = os.environ.get("SHINEON_CONCURRENT_WGRAD", "0") == "1"
 # SHINEON_DGRAD_IN_PLACE=0 goes back to a transposed copy per step (measured 0.05 ms/step slower).  The frozen VGG
 # chain always uses cached transposed weights.
 DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
-# LDS-resident attention core (csrc/attention.hip) for N <= 192, C in {128..512}, d in {32, 64}: one launch forward, two
-# backward, parity-tested (tests/test_models_gpu.py::test_self_attention_lds_resident_core).  Measured on MI355X
-# (tools/attn_bench.py, module fwd+bwd under graph replay, N = 12 / 48 / 192): 107 / 150 / 274 us against 89 / 111 / 152 us for
-# the GEMM + softmax composition - at B = 4 the fused kernels have 16-96 blocks and are latency chains, while the composed
-# path's ~10 us launches already sit near the launch floor.  Hence OFF by default; SHINEON_FUSED_ATTENTION=1 switches it on.
-FUSED_ATTENTION = os.environ.get("SHINEON_FUSED_ATTENTION", "0") == "1"
 # Split-bf16 convolutions for the FROZEN VGG19 chain (csrc/sb16.hip): fp32 = hi + mid bf16 planes, three bf16 MFMAs per
 # product instead of one fp32 MFMA stream at 1/16 of the rate.  Not bit-equal to the fp32 path (error ~3x the fp32 MFMA
 # chain's own round-off), so it is OFF by default and reported as its own bench line (bench.py --vgg-split-bf16).
 VGG_SPLIT_BF16 = os.environ.get("SHINEON_VGG_SPLIT_BF16", "0") == "1"
+# Winograd F(2x2, 3x3) for the frozen VGG19 chain (csrc/wino.hip): fp32 arithmetic, 2.25x fewer MFMA FLOPs.
+#   "fused"    one launch: input transform at fragment-build time, 16 GEMMs, output transform through LDS
+#   "nonfused" transform / batched GEMM / transform (pays 4x the activation size in transformed operands)
+#   "auto"     per layer from the measured crossover (tools/wino_bench.py)
+#   "0"        direct implicit GEMM everywhere
+WINOGRAD = os.environ.get("SHINEON_WINOGRAD", "auto")
+
 
 
 class _SideStream:
@@ -787,17 +788,14 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
         a, o = f(b * n, n), f(b * n, c)
         out = nhwc_empty(b, h, w, c, dev)
-        ctx.core_fused = bool(FUSED_ATTENTION and L.so_attention_supported(n, c, d))
-        if ctx.core_fused:
-            # energy -> softmax -> attention x V -> gamma * o + x in ONE LDS-resident kernel (csrc/attention.hip)
-            check(L.so_attention_fwd(qp, E, d, xp, ldx, gamma.data_ptr(), out.data_ptr(), c, a.data_ptr(), o.data_ptr(),
-                                     b, n, c, _stream()), "attention_fwd")
-        else:
-            e = f(b * n, n)
-            _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
-            check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
-            _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
-            check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
+        # energy -> softmax -> attention x V -> gamma * o + x as batched GEMMs + row softmax (an LDS-resident single-kernel core
+        # was built and measured slower at B = 4 - 16-96 blocks of dependent MFMA chains against launches already at the
+        # ~10 us floor - and removed in round 3)
+        e = f(b * n, n)
+        _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
+        check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
+        _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
+        check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
         ctx.save_for_backward(x, qkv, a, o, gamma)
         ctx.params = (wq, bq, gamma)  # first tensors of the adjacent weight / bias runs, and gamma
         return out
@@ -821,18 +819,13 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
         dqkv = f(b * n, E)
         de = f(b * n, n)
-        if ctx.core_fused:
-            # two launches: per 32 queries (da, softmax backward, dq), per 32 keys (dk, dv)
-            check(L.so_attention_bwd(qp, E, d, gp, ldg, a.data_ptr(), gm, de.data_ptr(), dqkv.data_ptr(), b, n, c, _stream()),
-                  "attention_bwd")
-        else:
-            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + d * 4, dqkv.data_ptr() + 2 * d * 4
-            _gemm(1, 0, n, c, n, a.data_ptr(), n, n * n, gp, ldg, n * ldg, dvp, E, n * E, b, alpha=gm, device=dev)
-            da = f(b * n, n)
-            _gemm(0, 1, n, n, c, gp, ldg, n * ldg, vp, E, n * E, da.data_ptr(), n, n * n, b, alpha=gm, device=dev)
-            check(L.so_softmax_rows_bwd(a.data_ptr(), n, da.data_ptr(), n, de.data_ptr(), n, b * n, n, _stream()), "softmax_bwd")
-            _gemm(0, 0, n, d, n, de.data_ptr(), n, n * n, kp, E, n * E, dqp, E, n * E, b, device=dev)
-            _gemm(1, 0, n, d, n, de.data_ptr(), n, n * n, qp, E, n * E, dkp, E, n * E, b, device=dev)
+        dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + d * 4, dqkv.data_ptr() + 2 * d * 4
+        _gemm(1, 0, n, c, n, a.data_ptr(), n, n * n, gp, ldg, n * ldg, dvp, E, n * E, b, alpha=gm, device=dev)
+        da = f(b * n, n)
+        _gemm(0, 1, n, n, c, gp, ldg, n * ldg, vp, E, n * E, da.data_ptr(), n, n * n, b, alpha=gm, device=dev)
+        check(L.so_softmax_rows_bwd(a.data_ptr(), n, da.data_ptr(), n, de.data_ptr(), n, b * n, n, _stream()), "softmax_bwd")
+        _gemm(0, 0, n, d, n, de.data_ptr(), n, n * n, kp, E, n * E, dqp, E, n * E, b, device=dev)
+        _gemm(1, 0, n, d, n, de.data_ptr(), n, n * n, qp, E, n * E, dkp, E, n * E, b, device=dev)
         # dx = dout + [dq | dk | dv] [Wq; Wk; Wv]
         dx = nhwc_empty(b, h, w, c, dev)
         _gemm(0, 0, b * n, c, E, dqkv.data_ptr(), E, 0, wq.data_ptr(), c, 0, dx.data_ptr(), c, 0, 1, res=gp, ldres=ldg, device=dev)
@@ -1398,6 +1391,64 @@ def _sb16_weights(wk, owner, transpose):
         _SB16_W_CACHE[key] = (ref, version, hi, mid)
     return hi, mid
 
+_WINO_W_CACHE = {}
+
+
+def _wino_mode(ci, co, n, h, w):
+    """Which kernel computes a 3x3 / s1 / p1 convolution with ci -> co channels on n x h x w pixels: "direct", "fused" or
+    "nonfused".  The auto rule is the measured crossover on MI355X (tools/wino_bench.py, profiles/r03_wino_bench.csv)."""
+    if WINOGRAD in ("0", "off", "direct") or ci % 4 or co % 4 or min(ci, co) < 32:
+        return "direct"
+    if WINOGRAD in ("fused", "nonfused"):
+        return WINOGRAD
+    tw, th = (w + 1) // 2, (h + 1) // 2
+    blocks = n * ((tw + 7) // 8) * ((th + 3) // 4) * ((co + 63) // 64)   # fused kernel: one block per (8x4-tile patch, 64 ko)
+    if blocks < 256:   # cannot fill the 256 CUs: the 16-GEMM batch of the non-fused form has 16x the blocks
+        return "nonfused" if min(ci, co) >= 128 else "direct"
+    return "fused"
+
+
+def _wino_weights(wk, owner, transpose, fused=False):
+    """Winograd-domain weights of the OHWI tensor `wk` (Ko, 3, 3, C): U[16][Ko][C], or for the input gradient U'[16][C][Ko]
+    (flipped taps); fused=True: the fused kernel's [K/8][16][N][8] order.  `owner` = (weakref to the parameter, its version): frozen weights are transformed once and cached per
+    parameter object and version like the transposed copies; owner None transforms on every call (trainable weights)."""
+    ko, _, _, c = wk.shape
+    L = lib()
+    key = None
+    numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else 16 * ko * c
+    if owner is not None:
+        ref, version = owner
+        p = ref()
+        key = (id(p), bool(transpose), bool(fused))
+        hit = _WINO_W_CACHE.get(key) if p is not None else None
+        if hit is not None and hit[0]() is p and hit[1] == version and hit[2].numel() == numel:
+            return hit[2]
+    u = torch.empty(numel, dtype=torch.float32, device=wk.device)
+    fn = L.so_wino_fused_weights if fused else L.so_wino_weights
+    check(fn(wk.data_ptr(), u.data_ptr(), ko, ko, c, int(transpose), _stream()), "wino_weights")
+    if key is not None and owner[0]() is not None:
+        for k in [k for k, v in _WINO_W_CACHE.items() if v[0]() is None]:
+            del _WINO_W_CACHE[k]
+        _WINO_W_CACHE[key] = (owner[0], owner[1], u)
+    return u
+
+
+def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, device, lane=4, fused=False):
+    """y = gate(act(conv3x3(x) + bias)) through F(2x2,3x3); u = _wino_weights(...) with N = co rows of K = ci columns."""
+    L = lib()
+    if fused:
+        check(L.so_wino_fused_conv3x3(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, 0.0,
+                                      _stream()), "wino_fused_conv3x3")
+        return
+    need = L.so_wino_ws_floats(n, h, w, ci, co) * 4
+    wws = workspace(device, need, lane=lane)   # transformed operands: their own slab (split-K slabs live in lane 0)
+    ws = workspace(device)
+    check(L.so_wino_conv3x3(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
+                            bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, 0.0,
+                            wws.data_ptr(), wws.numel() * 4, ws.data_ptr(), ws.numel() * 4, _stream()), "wino_conv3x3")
+
+
 # ------------------------------------------------------------------------------------------------
 # VGG19 perceptual loss as ONE autograd node (models/networks/loss.py:106-122 + vgg.py:6-36)
 # ------------------------------------------------------------------------------------------------
@@ -1464,6 +1515,11 @@ class _VggLossFn(torch.autograd.Function):
                                             None, out.data_ptr(), co, oh.data_ptr() if emit else None, om.data_ptr() if emit else None,
                                             n2, hh, ww, ci, co, 1, _stream()), "sb16_conv3x3")
                     planes = (oh, om) if emit else None
+                elif _wino_mode(ci, co, n2, hh, ww) != "direct":
+                    fz = _wino_mode(ci, co, n2, hh, ww) == "fused"
+                    wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, wowner, False, fz), bias, None, out.data_ptr(), co, n2, hh, ww,
+                                 ci, co, ACT_RELU, dev, fused=fz)
+                    planes = None
                 else:
                     check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
                                             3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
@@ -1530,6 +1586,11 @@ class _VggLossFn(torch.autograd.Function):
                 wh, wm = _sb16_weights(wk, wkey, transpose=True)
                 check(L.so_sb16_conv3x3(gh.data_ptr(), gm.data_ptr(), wh.data_ptr(), wm.data_ptr(), None, gate, dx.data_ptr(), ci,
                                         None, None, b, hh, ww, co, ci, 0, _stream()), "sb16_dgrad")
+            elif _wino_mode(co, ci, b, hh, ww) != "direct":
+                # input gradient = the same Winograd convolution on flipped taps with C and Ko swapped (U'[16][ci][co])
+                fz = _wino_mode(co, ci, b, hh, ww) == "fused"
+                wino_conv3x3(g.data_ptr(), co, _wino_weights(wk, wkey, True, fz), None, gate, dx.data_ptr(), ci, b, hh, ww, co, ci,
+                             ACT_NONE, dev, fused=fz)
             else:
                 wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
                 check(L.so_conv2d_dgrad_t_gated(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, gate, b, hh, ww, ci, co, 3, 3, 1, 1,
@@ -1567,8 +1628,13 @@ def vgg_target_features(y, cfg, params):
             co = weight.shape[0]
             wk = _ohwi(weight, cpad=ci)
             out = nhwc_empty(n2, hh, ww, co, dev)
-            check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
-                                    3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
+            mode = _wino_mode(ci, co, n2, hh, ww)
+            if mode != "direct":
+                wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, (weakref.ref(weight), weight._version), False, mode == "fused"),
+                             bias, None, out.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, dev, fused=mode == "fused")
+            else:
+                check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
+                                        3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
             if item[1] is not None:
                 feats.append(out)
         cur = out

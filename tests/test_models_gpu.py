@@ -571,55 +571,6 @@ def test_trainer_graph_overlap_mode_equals_eager_mode(cuda, tmp_path):
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
-@pytest.mark.parametrize("c,hw", [(512, (4, 3)), (512, (8, 6)), (512, (16, 12)), (256, (8, 6)), (256, (6, 6))])
-def test_self_attention_lds_resident_core(cuda, c, hw):
-    """The LDS-resident attention core (csrc/attention.hip: energy -> softmax -> AV -> gamma*o + x in one launch, the
-    backward in two) against the oracle (sagan.py:29-54) at the U-Net's own sizes N = 12 / 48 / 192, C = 512, d = 64, plus
-    a ragged N = 36; and against the GEMM + softmax composition it replaces."""
-    from oracle.procedural import procedural_state_dict
-    from shineon_virtual_tryon_amd import ops
-    from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
-    from shineon_virtual_tryon_amd.optim import HipAdam
-
-    def run(fused):
-        ops.FUSED_ATTENTION = fused
-        sa = SelfAttention(c)
-        sd = procedural_state_dict({k: tuple(v.shape) for k, v in sa.state_dict().items()}, seed=11)
-        sd["gamma"] = torch.tensor([0.7])
-        sa.load_state_dict(sd)
-        sa = sa.to(cuda)
-        opt = HipAdam(sa.parameters(), lr=1e-3, adjacent=sa.adjacent_param_groups())
-        opt.zero_grad()
-        x = torch.randn(4, c, hw[0], hw[1], generator=torch.Generator().manual_seed(12))
-        xg = x.clone().to(cuda).requires_grad_(True)
-        y = sa(xg)
-        assert type(y.grad_fn).__name__.startswith("_SelfAttentionQkvFn")
-        seed = torch.randn(y.shape, generator=torch.Generator().manual_seed(13))
-        (y * seed.to(cuda)).sum().backward()
-        torch.cuda.synchronize()
-        return sd, x, seed, y.detach().cpu(), xg.grad.cpu(), {n: p.grad.detach().cpu().clone() for n, p in sa.named_parameters()}
-
-    default = ops.FUSED_ATTENTION
-    try:
-        sd, x, seed, y1, dx1, g1 = run(True)
-        _, _, _, y0, dx0, g0 = run(False)
-    finally:
-        ops.FUSED_ATTENTION = default
-    assert ops.lib().so_attention_supported(hw[0] * hw[1], c, c // 8) == 1
-    xc = x.clone().requires_grad_(True)
-    pc = {"a." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    yr = oracle.self_attention(xc, pc, "a")
-    (yr * seed).sum().backward()
-    assert_close(y1, yr, atol=2e-5, what="fused core: out")
-    assert_close(dx1, xc.grad, atol=1e-4, what="fused core: dx")
-    for name, g in g1.items():
-        ref = pc["a." + name].grad
-        assert_close(g, ref, atol=1e-4 + 1e-4 * float(ref.abs().max()), what=f"fused core: d{name}")
-        assert_close(g, g0[name], atol=1e-4 + 1e-4 * float(ref.abs().max()), what=f"fused vs composed: d{name}")
-    assert_close(y1, y0, atol=1e-5, what="fused vs composed: out")
-    assert_close(dx1, dx0, atol=5e-5, what="fused vs composed: dx")
-
-
 def test_vgg_split_bf16_path_stays_within_the_fp32_parity_tolerances(cuda):
     """Opt-in split-bf16 VGG chain (csrc/sb16.hip: fp32 = hi + mid bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate):
     perceptual loss and its input gradient against the oracle at the SAME tolerances as the fp32 path, and the full bs = 2

@@ -380,3 +380,82 @@ def test_adam_matches_torch(ops, cuda):
         opt.step()
         ops.adam_step(p, g.to(cuda), m, v, 1e-2, 0.9, 0.999, 1e-8, s)
     assert_close(p, p_ref.detach(), atol=1e-6, what="adam")
+
+
+# ------------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
+@pytest.mark.parametrize("n,h,w,c,ko,act,gated", [
+    (2, 16, 12, 64, 32, 1, False),     # ReLU epilogue (VGG forward)
+    (1, 7, 5, 8, 12, 0, False),        # odd H and W: ragged last tile row / column
+    (3, 8, 6, 128, 128, 0, True),      # gate = ReLU backward fused (VGG input gradient)
+    (8, 32, 24, 256, 512, 1, False),   # VGG conv4_1 at 2B = 8 images
+])
+def test_winograd_conv3x3_matches_fp64_convolution(cuda, ops, n, h, w, c, ko, act, gated):
+    """csrc/wino.hip against an fp64 convolution of the same operands, next to the direct implicit-GEMM kernel: the
+    Winograd result must be as close to the exact value as the direct fp32 sum is (within 4x its error + 2e-6 of max)."""
+    from shineon_virtual_tryon_amd import lib
+
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = rnd(n, h, w, c, seed=1)
+    wt = rnd(ko, 3, 3, c, seed=2, scale=(2.0 / (9 * c)) ** 0.5)
+    bias = rnd(ko, seed=3, scale=0.1)
+    gate = rnd(n, h, w, ko, seed=4) if gated else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.permute(0, 3, 1, 2).double(), bias.double(), padding=1)
+    ref = (ref.relu() if act else ref).permute(0, 2, 3, 1)
+    if gated:
+        ref = torch.where(gate.double() > 0, ref, torch.zeros_like(ref))
+    xd, wd, bd = x.to(cuda), wt.to(cuda), bias.to(cuda)
+    gd = gate.to(cuda) if gated else None
+    u = torch.empty(16, ko, c, device=cuda)
+    assert L.so_wino_weights(wd.data_ptr(), u.data_ptr(), ko, ko, c, 0, st) == 0
+    wws = torch.empty(L.so_wino_ws_floats(n, h, w, c, ko), device=cuda)
+    ws = ops.workspace(cuda)
+    y = torch.full((n, h, w, ko), float("nan"), device=cuda)
+    assert L.so_wino_conv3x3(xd.data_ptr(), c, u.data_ptr(), bd.data_ptr(), ko, gd.data_ptr() if gated else None, y.data_ptr(), ko,
+                             n, h, w, c, ko, act, 0.0, wws.data_ptr(), wws.numel() * 4, ws.data_ptr(), ws.numel() * 4, st) == 0
+    yd = torch.empty_like(y)
+    assert L.so_conv2d_fprop(xd.data_ptr(), c, wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), ko, n, h, w, c, ko, 3, 3, 1, 1, act, 0.0,
+                             ws.data_ptr(), ws.numel() * 4, st) == 0
+    if gated:
+        yd = torch.where(gd > 0, yd, torch.zeros_like(yd))
+    big = float(ref.abs().max())
+    e_w, e_d = float((y.cpu().double() - ref).abs().max()), float((yd.cpu().double() - ref).abs().max())
+    print(f"winograd {n}x{h}x{w} {c}->{ko}: max err {e_w:.2e} (direct {e_d:.2e}), max |y| {big:.2f}")
+    assert e_w <= 4 * e_d + 2e-6 * big, (e_w, e_d, big)
+    # the fused single-launch form (weights in its own [c/8][xi][ko][8] order)
+    uf = torch.empty(L.so_wino_fused_weight_floats(ko, c, 0), device=cuda)
+    assert L.so_wino_fused_weights(wd.data_ptr(), uf.data_ptr(), ko, ko, c, 0, st) == 0
+    y2 = torch.full((n, h, w, ko), float("nan"), device=cuda)
+    assert L.so_wino_fused_conv3x3(xd.data_ptr(), c, uf.data_ptr(), bd.data_ptr(), ko, gd.data_ptr() if gated else None, y2.data_ptr(),
+                                   ko, n, h, w, c, ko, act, 0.0, st) == 0
+    e_f = float((y2.cpu().double() - ref).abs().max())
+    print(f"   fused: max err {e_f:.2e}")
+    assert e_f <= 4 * e_d + 2e-6 * big, (e_f, e_d, big)
+
+
+def test_winograd_input_gradient_is_the_flipped_transposed_convolution(cuda, ops):
+    """dx of a 3x3 / s1 / p1 convolution through so_wino_weights(flip_transpose=1) + so_wino_conv3x3 against autograd (fp64)."""
+    from shineon_virtual_tryon_amd import lib
+
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    n, h, w, c, ko = 2, 16, 12, 64, 128
+    x = rnd(n, c, h, w, seed=5).double().requires_grad_(True)
+    wt = rnd(ko, 3, 3, c, seed=6, scale=0.05)
+    dy = rnd(n, h, w, ko, seed=7)
+    F.conv2d(x, wt.permute(0, 3, 1, 2).double(), padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    ref = x.grad.permute(0, 2, 3, 1)
+    wd, dyd = wt.to(cuda), dy.to(cuda)
+    u = torch.empty(16, c, ko, device=cuda)
+    assert L.so_wino_weights(wd.data_ptr(), u.data_ptr(), ko, ko, c, 1, st) == 0
+    wws = torch.empty(L.so_wino_ws_floats(n, h, w, ko, c), device=cuda)
+    ws = ops.workspace(cuda)
+    dx = torch.empty(n, h, w, c, device=cuda)
+    assert L.so_wino_conv3x3(dyd.data_ptr(), ko, u.data_ptr(), None, 0, None, dx.data_ptr(), c, n, h, w, ko, c, 0, 0.0,
+                             wws.data_ptr(), wws.numel() * 4, ws.data_ptr(), ws.numel() * 4, st) == 0
+    assert_close(dx, ref.float(), atol=3e-6 * float(ref.abs().max()), what="winograd input gradient")
+    uf = torch.empty(L.so_wino_fused_weight_floats(ko, c, 1), device=cuda)
+    assert L.so_wino_fused_weights(wd.data_ptr(), uf.data_ptr(), ko, ko, c, 1, st) == 0
+    dx2 = torch.full((n, h, w, c), float("nan"), device=cuda)
+    assert L.so_wino_fused_conv3x3(dyd.data_ptr(), ko, uf.data_ptr(), None, 0, None, dx2.data_ptr(), c, n, h, w, ko, c, 0, 0.0, st) == 0
+    assert_close(dx2, ref.float(), atol=3e-6 * float(ref.abs().max()), what="fused winograd input gradient")

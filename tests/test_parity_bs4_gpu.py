@@ -70,7 +70,24 @@ def oracle_unet(sd, batch_cpu, hp, dtype=torch.float32):
     return params, ref
 
 
-def compare_all_gradients(model, ref32, ref64, what, rel=GRAD_REL):
+def kink_spread(run64, exact):
+    """{name: max |gradient(ReLU / LeakyReLU kinks moved by +-1e-5 of the tensor's magnitude) - gradient(kinks at 0)|} from
+    two more fp64 oracle runs (sams_helpers.kink_shift).  Two fp32 evaluations agree on a pre-activation to ~1e-6 of its
+    magnitude; an element that close to 0 takes either side of the kink, and its whole gradient cone changes by the slope
+    difference.  The spread is exactly 0 for a tensor no such element reaches."""
+    from sams_helpers import kink_shift
+
+    spread = {}
+    for sign in (1.0, -1.0):
+        with kink_shift(sign * 1e-5):
+            shifted = run64()
+        for k, v in shifted.items():
+            if v.grad is not None and exact[k].grad is not None:
+                spread[k] = max(spread.get(k, 0.0), float((v.grad - exact[k].grad).abs().max()))
+    return spread
+
+
+def compare_all_gradients(model, ref32, ref64, what, rel=GRAD_REL, kink=None):
     """Element-wise comparison of EVERY trainable parameter's gradient; one assertion listing every offender.
 
     ref32 = the oracle in fp32 (the reference's CPU evaluation), ref64 = the same graph evaluated in fp64 (the exact
@@ -82,6 +99,10 @@ def compare_all_gradients(model, ref32, ref64, what, rel=GRAD_REL):
         reference's own round-off max|g32 - g64| next to ours),
       * a scalar gradient (attention gamma = one heavily cancelling dot product) may instead be within 10x the fp32
         reference's own distance from fp64 (both carry condition-number x eps of relative error),
+      * kink: a callable returning kink_spread(...) - a tensor that fails the rules above may use the bracket of the fp64
+        gradient under +-1e-5 shifts of every ReLU kink (the WarpModel's Conv -> ReLU -> BatchNorm: at bs = 8 one
+        pre-activation within 1e-7 of zero lands on the other side and moves one output channel's weight / bias gradient by
+        1-3 % of the tensor's max; the bracket is 0 for every tensor without such an element),
       * analytically-zero gradients (fp64 value six orders of magnitude below the fp32 reference value: a bias in
         front of an Instance/BatchNorm, the key bias of a softmax attention) hold pure round-off noise in the
         reference; ours must be no larger than 10x that noise (the HIP path writes exact zeros for the norm case).
@@ -112,6 +133,12 @@ def compare_all_gradients(model, ref32, ref64, what, rel=GRAD_REL):
                 # 3-13 % across runs with different split-K plans): within 30x of it
                 ok = e64 <= 30 * r
                 tag = "fp64-scalar"
+            if not ok and kink is not None:
+                # kink bracket (see kink_spread): only evaluated when a tensor needs it, then cached for the rest
+                if callable(kink):
+                    kink = kink()
+                ok = min(e32, e64) <= rel * s64 + GRAD_FLOOR + 1.5 * kink.get(name, 0.0)
+                tag = "fp64+kink"
             via64.append((name, e32 / max(s32, 1e-30), e64 / max(s64, 1e-30), r / max(s64, 1e-30)))
         rows.append((name, tag, e32, s32, e64, s64, r))
         if not ok:
@@ -183,7 +210,8 @@ def test_warp_model_bs4_all_outputs_and_every_gradient(cuda):
         grid, theta = twin(person, batch["cloth"])
     _check_warp_outputs(model.warped_cloth, grid, theta, ref, batch_cpu)
     assert abs(float(res.minimize) - float(ref["loss/G"])) <= 2e-5, (float(res.minimize), float(ref["loss/G"]))
-    n = compare_all_gradients(model, p32, p64, "WarpModel bs=4")
+    n = compare_all_gradients(model, p32, p64, "WarpModel bs=4",
+                              kink=lambda: kink_spread(lambda: oracle_warp(sd, batch_cpu, torch.float64)[0], p64))
     assert n == 62  # 2 x (6 conv + 5 BN) x (w, b) + regression (4 conv + 4 BN + linear) x (w, b)
     msd = model.state_dict()
     for k, v in bn.items():
@@ -237,7 +265,8 @@ def test_chained_step_through_the_timed_schedule(cuda, bs):
     w64, _ = oracle_warp(wsd, batch_cpu, torch.float64)
     assert abs(float(g.result_warp.minimize) - float(wref["loss/G"])) <= 2e-5
     assert_close(g.warped, wref["warped_cloth"], atol=1e-4, what="chained: warped cloth")
-    compare_all_gradients(warp, w32, w64, f"chained/warp bs={bs} (graph replay)")
+    compare_all_gradients(warp, w32, w64, f"chained/warp bs={bs} (graph replay)",
+                          kink=lambda: kink_spread(lambda: oracle_warp(wsd, batch_cpu, torch.float64)[0], w64))
 
     b2 = dict(batch_cpu)
     b2["cloth"] = g.cloth_tryon.detach().cpu().contiguous()
