@@ -311,22 +311,27 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  f32x4 ra, rb[4];
+  // Register-side prefetch ring of TWO stages: the loads of step s + 3 are issued during step s and written to LDS during
+  // step s + 2, i.e. they have two full K steps (~4000 cycles) to land.  With one block per CU nothing else hides an HBM
+  // miss on the activation patch (a new 128-byte line per pixel every fourth step); with a one-stage ring the kernel sat at
+  // 43 % of the MFMA rate (profiles/r03_b_wino_bench.csv).  The K loop is unrolled by two so that the ring is indexed
+  // statically; an odd trailing step multiplies zeros (past-the-end loads return 0).
+  f32x4 ra0, ra1, rb0[4], rb1[4];
   {
-    f32x4 ra0, rb0[4];
-    ra0 = load_a(0);
-    load_b(0, rb0);
-    ra = load_a(1);
-    load_b(1, rb);
-    store_a(0, ra0);
-    store_b(0, rb0);
+    f32x4 a0 = load_a(0), b0[4];
+    load_b(0, b0);
+    ra0 = load_a(1);
+    load_b(1, rb0);
+    ra1 = load_a(2);
+    load_b(2, rb1);
+    store_a(0, a0);
+    store_b(0, b0);
   }
   __syncthreads();
 
-  int cur = 0;
-  for (int s = 0; s < p.nks; ++s) {
-    const float* as = As + cur * WF_ASTAGE;
-    const float* bs = Bs + cur * WF_BSTAGE;
+  auto kstep = [&](int rd, f32x4& ra, f32x4 (&rb)[4], int s_next) {
+    const float* as = As + rd * WF_ASTAGE;
+    const float* bs = Bs + rd * WF_BSTAGE;
     f32x4 d1[4], d2[4], bf[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -350,18 +355,21 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
     WF_SB();
-    store_a(cur ^ 1, ra);
-    store_b(cur ^ 1, rb);
+    store_a(rd ^ 1, ra);     // the stage consumed by the NEXT step (its loads were issued two steps ago)
+    store_b(rd ^ 1, rb);
     WF_SB();
 #pragma unroll
     for (int e = 2; e < 4; ++e)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
     WF_SB();
-    ra = load_a(s + 2);
-    load_b(s + 2, rb);
+    ra = load_a(s_next);
+    load_b(s_next, rb);
     __syncthreads();
-    cur ^= 1;
+  };
+  for (int s = 0; s < p.nks; s += 2) {
+    kstep(0, ra0, rb0, s + 3);
+    kstep(1, ra1, rb1, s + 4);
   }
 
   // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------

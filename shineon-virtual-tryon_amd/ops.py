@@ -324,14 +324,21 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wd + 2 * pad - s) // stride + 1
         y = nhwc_empty(n, ho, wo, op, x.device)
         ws = workspace(x.device)
-        check(
-            L.so_conv2d_fprop_padded(
-                xr.data_ptr(), _ld(xr), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                y.data_ptr(), op, n, h, wd, cp, op, o, r, s, stride, pad, act, float(act_param),
-                ws.data_ptr(), ws.numel() * 4, _stream(),
-            ),
-            "conv2d_fprop",
-        )
+        wino = _wino_mode(cp, op, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1) else "direct"
+        if wino != "direct":
+            # 3x3 / s1 / p1 (U-Net up path, GMM, SPADE): Winograd F(2x2,3x3); trainable weights are transformed per call
+            u = _wino_weights(w, None, False, fused=wino == "fused", ko_pad=op)
+            wino_conv3x3(xr.data_ptr(), _ld(xr), u, bias, None, y.data_ptr(), op, n, h, wd, cp, op, act, x.device,
+                         fused=wino == "fused", act_param=act_param)
+        else:
+            check(
+                L.so_conv2d_fprop_padded(
+                    xr.data_ptr(), _ld(xr), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                    y.data_ptr(), op, n, h, wd, cp, op, o, r, s, stride, pad, act, float(act_param),
+                    ws.data_ptr(), ws.numel() * 4, _stream(),
+                ),
+                "conv2d_fprop",
+            )
         ctx.save_for_backward(xr, w, y if act != ACT_NONE and not act_grad_external else None)
         # act_grad_external: the consumer (a BatchNorm told so) applies the activation's mask to the gradient it sends
         ctx.cfg = (stride, pad, ACT_NONE if act_grad_external else act, i, cp, op, bias is not None, tuple(weight.shape),
@@ -426,7 +433,13 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
-            if DGRAD_IN_PLACE:
+            wino = _wino_mode(op, cp, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1) else "direct"
+            if wino != "direct":
+                # the input gradient of a 3x3 / s1 / p1 convolution = the same convolution with flipped taps, C <-> Ko
+                u = _wino_weights(w, None, True, fused=wino == "fused", ko_pad=op)
+                wino_conv3x3(dy.data_ptr(), _ld(dy), u, None, None, dxp.data_ptr(), cp, n, h, wd, op, cp, ACT_NONE, dev,
+                             fused=wino == "fused")
+            elif DGRAD_IN_PLACE:
                 # trainable weights change every step: read them in place (OHWI rows are contiguous along the GEMM
                 # column c; the engine transposes while staging) instead of writing a transposed copy per step
                 check(
@@ -1403,16 +1416,21 @@ def _wino_mode(ci, co, n, h, w):
         return WINOGRAD
     tw, th = (w + 1) // 2, (h + 1) // 2
     blocks = n * ((tw + 7) // 8) * ((th + 3) // 4) * ((co + 63) // 64)   # fused kernel: one block per (8x4-tile patch, 64 ko)
-    if blocks < 256:   # cannot fill the 256 CUs: the 16-GEMM batch of the non-fused form has 16x the blocks
-        return "nonfused" if min(ci, co) >= 128 else "direct"
-    return "fused"
+    # measured (profiles/r03_wino_bench.csv): the fused kernel wins while the transformed operands of the non-fused form
+    # (16 / 4 x the activation size, written and read once each) outweigh its better GEMM: up to 128 channels from 64x48x4
+    # pixels, up to 256 channels from 64x48x8 pixels; the deep layers (256..512 channels at <= 32x24) go to the 16-GEMM batch
+    px, cmin = n * h * w, min(ci, co)
+    if blocks >= 256 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
+        return "fused"
+    return "nonfused" if cmin >= 128 else ("fused" if blocks >= 256 else "direct")
 
 
-def _wino_weights(wk, owner, transpose, fused=False):
+def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):
     """Winograd-domain weights of the OHWI tensor `wk` (Ko, 3, 3, C): U[16][Ko][C], or for the input gradient U'[16][C][Ko]
     (flipped taps); fused=True: the fused kernel's [K/8][16][N][8] order.  `owner` = (weakref to the parameter, its version): frozen weights are transformed once and cached per
     parameter object and version like the transposed copies; owner None transforms on every call (trainable weights)."""
-    ko, _, _, c = wk.shape
+    kw, _, _, c = wk.shape
+    ko = kw if ko_pad is None else ko_pad   # output channels zero-padded to a multiple of 4 (rows >= kw are zero)
     L = lib()
     key = None
     numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else 16 * ko * c
@@ -1425,7 +1443,7 @@ def _wino_weights(wk, owner, transpose, fused=False):
             return hit[2]
     u = torch.empty(numel, dtype=torch.float32, device=wk.device)
     fn = L.so_wino_fused_weights if fused else L.so_wino_weights
-    check(fn(wk.data_ptr(), u.data_ptr(), ko, ko, c, int(transpose), _stream()), "wino_weights")
+    check(fn(wk.data_ptr(), u.data_ptr(), ko, kw, c, int(transpose), _stream()), "wino_weights")
     if key is not None and owner[0]() is not None:
         for k in [k for k, v in _WINO_W_CACHE.items() if v[0]() is None]:
             del _WINO_W_CACHE[k]
@@ -1433,19 +1451,19 @@ def _wino_weights(wk, owner, transpose, fused=False):
     return u
 
 
-def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, device, lane=4, fused=False):
+def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, device, lane=4, fused=False, act_param=0.0):
     """y = gate(act(conv3x3(x) + bias)) through F(2x2,3x3); u = _wino_weights(...) with N = co rows of K = ci columns."""
     L = lib()
     if fused:
         check(L.so_wino_fused_conv3x3(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                      bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, 0.0,
-                                      _stream()), "wino_fused_conv3x3")
+                                      bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act,
+                                      float(act_param), _stream()), "wino_fused_conv3x3")
         return
     need = L.so_wino_ws_floats(n, h, w, ci, co) * 4
     wws = workspace(device, need, lane=lane)   # transformed operands: their own slab (split-K slabs live in lane 0)
     ws = workspace(device)
     check(L.so_wino_conv3x3(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
-                            bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, 0.0,
+                            bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, float(act_param),
                             wws.data_ptr(), wws.numel() * 4, ws.data_ptr(), ws.numel() * 4, _stream()), "wino_conv3x3")
 
 

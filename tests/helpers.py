@@ -54,7 +54,7 @@ def assert_grad_samples(get_grad, g, prefix, rel, what="", floor=2e-7):
     import re
 
     stride = int(re.match(r"gs(\d+)", prefix).group(1)) if re.match(r"gs(\d+)", prefix) else 97
-    keys = [k for k in g.files if k.startswith(prefix)]
+    keys = [k for k in (g.files if hasattr(g, "files") else g) if k.startswith(prefix)]
     bad = []
     for k in keys:
         ref = np.asarray(g[k], dtype=np.float64)

@@ -693,16 +693,27 @@ def test_sams_full_size_generator_pass_bs4_vs_oracle():
     prev_maps = batch["flow"][:, :n - 1].contiguous()
     maps = {k: batch[k][:, -1].contiguous() for k in ("agnostic", "densepose", "flow", "cloth")}
     gout = torch.randn(b, 4, h, w) / (h * w)
-    refs = []
-    for dtype in (torch.float32, torch.float64):
+    def run_oracle(dtype):
         osd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         for k, v in osd.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
                 v.requires_grad_(True)
         out = so.generator_forward(osd, prev_frames.to(dtype), prev_maps.to(dtype), {k: v.to(dtype) for k, v in maps.items()}, hp, True)
         out.backward(gout.to(dtype))
-        refs.append((out.detach(), {k[len("generator."):]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}))
-        del osd
+        return out.detach(), {k[len("generator."):]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}
+
+    refs = [run_oracle(torch.float32), run_oracle(torch.float64)]
+
+    def kinks():
+        """sams_helpers.kink_spread for this single pass: the fp64 gradients with every ReLU kink moved by +-1e-5"""
+        spread = {}
+        for sign in (1.0, -1.0):
+            with sh.kink_shift(sign * 1e-5):
+                _, g = run_oracle(torch.float64)
+            for k, v in g.items():
+                spread[k] = max(spread.get(k, 0.0), (v - refs[1][1][k]).abs().max().item())
+        return spread
+
     y = gen(prev_frames.to(DEV), prev_maps.to(DEV), {k: v.to(DEV) for k, v in maps.items()})
     y.backward(gout.to(DEV))
     (o32, g32), (o64, g64) = refs
@@ -711,4 +722,4 @@ def test_sams_full_size_generator_pass_bs4_vs_oracle():
     print(f"[sams generator bs=4] output: |ours - fp32 oracle| {e32:.2e}, |ours - fp64| {e64:.2e}, |fp32 oracle - fp64| "
           f"{(o32.double() - o64).abs().max().item():.2e}, max {o64.abs().max().item():.3f}")
     assert min(e32, e64) <= 1e-4 * max(1.0, o64.abs().max().item())
-    _compare_grads({k: p.grad for k, p in gen.named_parameters() if p.grad is not None}, g32, g64, "generator bs=4 full size")
+    _compare_grads({k: p.grad for k, p in gen.named_parameters() if p.grad is not None}, g32, g64, "generator bs=4 full size", kink=kinks)

@@ -77,8 +77,8 @@ def main():
             else:
                 err_w = float((y1 - y0).abs().max())
             gf = 2.0 * nb * h * w * ko * 9 * c / 1e9
-            print(f"{nb},{h},{w},{c},{ko},{td:.1f},{gf / td * 1e-3:.1f},{tw:.1f},{gf / tw * 1e-3:.1f},{td / tw:.2f},-,{t_gemm:.1f},-,"
-                  f"{err_d:.2e},{err_w:.2e},fused_us={tf:.1f},fused_eq_tflops={gf / tf * 1e-3:.1f},fused_speedup={td / tf:.2f},"
+            print(f"{nb},{h},{w},{c},{ko},{td:.1f},{gf / td * 1e3:.1f},{tw:.1f},{gf / tw * 1e3:.1f},{td / tw:.2f},-,{t_gemm:.1f},-,"
+                  f"{err_d:.2e},{err_w:.2e},fused_us={tf:.1f},fused_eq_tflops={gf / tf * 1e3:.1f},fused_speedup={td / tf:.2f},"
                   f"fused_vs_direct_maxdiff={err_f:.2e}", flush=True)
 
 
