@@ -40,6 +40,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
+KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = executed MFMA FLOPs (direct-convolution FLOPs / 2.25)
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
 GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": None}  # None: the MFMA launches' own 2MNK sum
 WORKLOADS = {

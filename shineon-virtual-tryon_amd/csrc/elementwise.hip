@@ -609,6 +609,15 @@ __global__ __launch_bounds__(256) void blend_bwd_k(const float* __restrict__ a, 
 
 #define VEC_OK2(p1, l1, p2, l2, C) (((C) & 3) == 0 && ((l1) & 3) == 0 && ((l2) & 3) == 0 && al16(p1) && al16(p2))
 
+__global__ void counter_bump_k(unsigned* counter) { counter[0] += 1u; }
+
+// every store of the kernels in front of this node (same stream) is complete when it starts; the release makes them visible
+// system-wide before the flag moves
+__global__ void signal_store_k(unsigned* flag, const unsigned* counter) {
+  __threadfence_system();
+  __hip_atomic_store(flag, counter[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 extern "C" {
 
 int so_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C, int act,
@@ -887,6 +896,42 @@ int so_axpby(const float* x, float a, float* y, float b, long long n, void* stre
   hipLaunchKernelGGL(axpby_k, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, a, y, b,
                      (unsigned)n);
   return SO_LAUNCH_CHECK();
+}
+
+// ---- stream hand-off in the MIDDLE of a replayed hipGraph (data-parallel gradient exchange overlapped with backward) ----
+// External event nodes are not available to PyTorch-ROCm graphs, so "this gradient bucket is complete" is signalled through
+// memory: a one-thread kernel captured at that point of the backward pass stores the step counter into an 8-byte signal
+// word, and the communication stream executes hipStreamWaitValue32(word >= step) - a command-processor wait that occupies
+// no compute unit - before its all-reduce.  Measured (tools/probes/stream_wait_value.hip): the waiting stream is released
+// 0.6 ms into a 6.3 ms graph, i.e. when the signal node runs, not when the graph ends.
+long long so_signal_alloc(void) {
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess) return 0;
+  if (hipMemset(p, 0, 8) != hipSuccess) { (void)hipFree(p); return 0; }
+  return (long long)(uintptr_t)p;
+}
+
+int so_signal_free(long long ptr) { return ptr ? (int)hipFree((void*)(uintptr_t)ptr) : 0; }
+
+int so_signal_can_wait(void) {
+  int can = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) return 0;
+  return can;
+}
+
+int so_counter_bump(void* counter, void* stream) {
+  hipLaunchKernelGGL(counter_bump_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)counter);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_signal_store(void* flag, const void* counter, void* stream) {
+  hipLaunchKernelGGL(signal_store_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)flag, (const unsigned*)counter);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_stream_wait_ge(void* flag, int value, void* stream) {
+  return (int)hipStreamWaitValue32((hipStream_t)stream, flag, (uint32_t)value, hipStreamWaitValueGte, 0xFFFFFFFFu);
 }
 
 }  // extern "C"

@@ -539,9 +539,15 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // A wave that owns a single 32x32 output tile would issue every MFMA on the SAME accumulator; an instruction
   // slotted between two such dependent MFMAs costs a ~43-cycle bubble (MI355X_MICROARCH.md).  Such waves split the
   // K sum over two accumulators (even / odd k-pairs), added once in the epilogue.
-  // (Measured on MI355X: no gain for v_mfma_f32_32x32x2_f32, whose dependent latency equals its issue time, so
-  //  the split is disabled; kept as a switch.)
-  constexpr int KS = 1;
+  // (Round 1 measured no gain and left it off.  Round 3 PMC passes - profiles/r03_e_*_pmc.csv - show the 64x64 / 4-wave
+  //  instantiations at 42 % MFMA-pipe utilisation with the waves issue-stalled 59 % of the time, the 128x128 ones at 75 %:
+  //  re-measured with the split on (SO_KSPLIT=2): 57.4 vs 56.9 us on the 512x4608x768 weight gradient, 550.3 vs 550.6
+  //  frames/s for the step - still no gain, so the dependent chain is not the limiter; what the counters show instead is
+  //  tile quantisation (576 tiles on 256 CUs: the CUs holding 3 tiles run at 58 %, the average is 42 %).  Left off.)
+#ifndef SO_KSPLIT
+#define SO_KSPLIT 1
+#endif
+  constexpr int KS = (TM * TN == 1) ? SO_KSPLIT : 1;
   f32x16 acc[TM][TN], acc2[1];  // acc2 is dead code unless KS == 2
 #pragma unroll
   for (int i = 0; i < TM; ++i)

@@ -22,6 +22,7 @@
 // dominates that traffic (C, Ko >= 128).  See DESIGN.md 3.7 for the measured crossover.
 #include "common.h"
 #include "../../include/shineon_hip.h"
+#include "thin.h"   // so_prof_begin / so_prof_end (live HIP-event timing shared with the implicit-GEMM engine)
 
 extern "C" int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A, int lda, long long sa,
                                const float* B, int ldb, long long sb, float* C, int ldc, long long sc, int batch,
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void wino_output_k(const float* __restrict__ M
   const long long T = (long long)Nb * th * tw;
   const long long total = T * kq;
   const long long sx = T * Ko;
+  const float slope = act == SO_ACT_RELU ? 0.f : (act == SO_ACT_LEAKY ? act_param : 1.f);
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const long long tile = idx / kq;
     const int k = (int)(idx - tile * kq) * 4;
@@ -119,10 +121,8 @@ __global__ __launch_bounds__(256) void wino_output_k(const float* __restrict__ M
         const int w = 2 * tx + bb;
         if (w >= W) continue;
         f32x4 v = (bb == 0 ? s[a][0] + s[a][1] + s[a][2] : s[a][1] - s[a][2] - s[a][3]) + b;
-        if (act != SO_ACT_NONE) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = so_actf(act, v[q], act_param);
-        }
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * slope;   // none / ReLU / LeakyReLU
         const long long off = ((long long)(n * H + h) * W + w) * ldy + k;
         if (gate) {
           const f32x4 g = ld4(gate + off);
@@ -172,21 +172,23 @@ __global__ __launch_bounds__(256) void wino_weights_k(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------------------
 // FUSED F(2x2, 3x3): input transform, the 16 GEMMs and the output transform in ONE kernel - V and M never exist in HBM.
 //
-// Block = 512 threads (8 waves, 2 per SIMD), one per CU (87 KB LDS): a patch of 8 x 4 Winograd tiles (16 x 8 output pixels of
-// one image, 18 x 10 input pixels) x KB = 64 output channels x all 16 transform points.  Wave w owns transformed ROW
-// i = w & 3 (points xi = 4 i + j, j = 0..3) of output-channel group kg = w >> 2 (32 channels): four independent 32 x 32
-// accumulators, the MFMA M axis = the 32 tiles, N axis = output channels, K axis = input channels.
-// K loop, 8 input channels per step, double-buffered LDS, prefetch distance 2 (as in igemm2.hip):
+// Block = 256 threads (4 waves), TWO blocks per CU (54.5 KB LDS, <= 256 VGPRs): a patch of 8 x 4 Winograd tiles (16 x 8
+// output pixels of one image, 18 x 10 input pixels) x KB = 32 output channels x all 16 transform points.  Wave w owns
+// transformed ROW i = w (points xi = 4 i + j, j = 0..3): four independent 32 x 32 accumulators, MFMA M axis = the 32 tiles,
+// N axis = output channels, K axis = input channels.  (First version: 512 threads x 64 output channels, one block per CU -
+// nothing overlapped a block's prologue / epilogue and the C = 64 layers ran at 43 % of the MFMA rate; two independent
+// blocks per CU cover each other's ramps.)
+// K loop, 8 input channels per step, double-buffered LDS, two register stages in flight (below):
 //   * A stage: the RAW 18 x 10 input patch, 8 channels per pixel (straight 16-byte copies; image borders / padding are
 //     out-of-range buffer loads = 0).  The input transform happens when a wave builds its fragments ("transform at read"):
 //     row i of B^T d B needs two patch rows (a1, a2) and all four patch columns - 8 ds_read_b128 and 8 vector adds yield the
-//     four A fragments (one per j) for a lane's tile; each transformed value is consumed by exactly one wave pair, so
-//     nothing is computed twice.  Even / odd patch rows and columns are stored in separate halves (slot = x>>1 + (x&1)*9)
-//     with a 12-float pixel pitch and 24 slots per row: the stride-2 tile walk of the 16 lanes of a ds_read_b128 group then
-//     hits 16 distinct bank quads (derivation in DESIGN.md 3.7).
-//   * B stage: U[c/8][xi][ko][8] (so_wino_weights layout 2): the block's slice of one step is 16 contiguous 2 KB runs.
+//     four A fragments (one per j) for a lane's tile; each transformed value is consumed by exactly one wave, so nothing is
+//     computed twice.  Even / odd patch rows and columns are stored in separate halves (slot = x>>1 + (x&1)*9) with a
+//     12-float pixel pitch and 24 slots per row: the stride-2 tile walk of the 16 lanes of a ds_read_b128 group then hits
+//     16 distinct bank quads (derivation in DESIGN.md 3.7).
+//   * B stage: U[c/8][xi][ko][8] (so_wino_fused_weights): the block's slice of one step is 16 contiguous 1 KB runs.
 // Epilogue: A^T M A = column combination in registers (over the wave's four j accumulators), row combination through
-// LDS (8 planes of 32 x 64 floats), then bias / activation / ReLU gate and 16-byte pixel stores (256 B per pixel).
+// LDS (8 planes of 32 x 32 floats), then bias / activation / ReLU gate and 16-byte pixel stores (128 B per pixel).
 struct WinoP {
   const float* x;
   const float* U;
@@ -209,20 +211,21 @@ __device__ __forceinline__ f32x4 wf_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return r;
 }
 
-constexpr int WF_KB = 64;                  // output channels per block
+constexpr int WF_KB = 32;                  // output channels per block
+constexpr int WF_NT = 256;                 // threads per block
 constexpr int WF_APIX = 12;                // floats per pixel slot in the raw A stage (8 data + 4 pad)
 constexpr int WF_AROW = 24;                // pixel slots per patch row
 constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 2880 floats = 11.25 KB
-constexpr int WF_BSTAGE = 16 * WF_KB * 8;           // 8192 floats = 32 KB
-constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 88.5 KB; the epilogue re-uses the first 64 KB
+constexpr int WF_BSTAGE = 16 * WF_KB * 8;           // 4096 floats = 16 KB
+constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 54.5 KB; the epilogue re-uses the first 32 KB
+constexpr int WF_BQ = 16 * WF_KB * 2 / WF_NT;       // B quads per thread per step (4)
 
-__global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
+__global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * WF_ASTAGE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wi = wave & 3, kg = wave >> 2;
 
   // XCD-aware block -> (patch, ko block) map: XCD x works on the x-th contiguous eighth of the (patch, kb) order, so the
   // ko blocks of one patch (which re-read the same input pixels) and neighbouring patches (halo) share one L2
@@ -242,47 +245,57 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, (int)p.u_bytes, 0x00020000);
 
   // ---- loader state ------------------------------------------------------------------------------------------------
-  // A: threads 0..359 copy (pixel = tid >> 1, channel quad = tid & 1) of the 18 x 10 patch
-  int a_src = -1, a_dst = 0;
+  // A: 360 quads (pixel = id >> 1, channel quad = id & 1) of the 18 x 10 patch: ids tid and tid + 256
+  int a_src[2], a_dst[2];
   const int aq = tid & 1;
-  if (tid < 360) {
-    const int pix = tid >> 1;
-    const int ppy = pix / 18, ppx = pix - ppy * 18;
-    const int h = h_org + ppy, w = w_org + ppx;
-    if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) a_src = ((n * p.H + h) * p.W + w) * p.ldx + aq * 4;
-    const int rs = (ppy >> 1) + (ppy & 1) * 5, cs = (ppx >> 1) + (ppx & 1) * 9;
-    a_dst = (rs * WF_AROW + cs) * WF_APIX + aq * 4;
-  }
-  // B: 2048 quads per step = 4 per thread: quad id = tid + 512 m -> row = xi * 64 + ko_local, quad = id & 1
-  int b_src[4], b_dst[4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int qid = tid + 512 * m;
+  for (int m = 0; m < 2; ++m) {
+    const int id = tid + WF_NT * m;
+    a_src[m] = -1;
+    a_dst[m] = -1;
+    if (id < 360) {
+      const int pix = id >> 1;
+      const int ppy = pix / 18, ppx = pix - ppy * 18;
+      const int h = h_org + ppy, w = w_org + ppx;
+      if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) a_src[m] = ((n * p.H + h) * p.W + w) * p.ldx + aq * 4;
+      const int rs = (ppy >> 1) + (ppy & 1) * 5, cs = (ppx >> 1) + (ppx & 1) * 9;
+      a_dst[m] = (rs * WF_AROW + cs) * WF_APIX + aq * 4;
+    }
+  }
+  // B: 1024 quads per step = 4 per thread: quad id = tid + 256 m -> row = xi * 32 + ko_local, quad = id & 1
+  int b_src[WF_BQ], b_dst[WF_BQ];
+#pragma unroll
+  for (int m = 0; m < WF_BQ; ++m) {
+    const int qid = tid + WF_NT * m;
     const int row = qid >> 1, q = qid & 1;
-    const int xi = row >> 6, kol = row & 63;
+    const int xi = row / WF_KB, kol = row % WF_KB;
     b_src[m] = (k0 + kol < p.Ko) ? (xi * p.Ko + k0 + kol) * 8 + q * 4 : -1;
     b_dst[m] = row * 8 + ((q ^ ((row >> 3) & 1)) << 2);
   }
   const int b_step = 16 * p.Ko * 8;   // floats per K step in U
 
-  auto load_a = [&](int s) -> f32x4 {
+  auto load_a = [&](int s, f32x4 (&dst)[2]) {
     const int c = 8 * s + aq * 4;
-    const bool ok = (a_src >= 0) & (c < p.C);
-    return wf_bload(rX, ok ? (unsigned)(a_src + 8 * s) * 4u : WF_OOB);
-  };
-  auto load_b = [&](int s, f32x4 (&dst)[4]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 2; ++m) {
+      const bool ok = (a_src[m] >= 0) & (c < p.C);
+      dst[m] = wf_bload(rX, ok ? (unsigned)(a_src[m] + 8 * s) * 4u : WF_OOB);
+    }
+  };
+  auto load_b = [&](int s, f32x4 (&dst)[WF_BQ]) {
+#pragma unroll
+    for (int m = 0; m < WF_BQ; ++m) {
       const bool ok = (b_src[m] >= 0) & (s < p.nks);
       dst[m] = wf_bload(rU, ok ? (unsigned)(b_src[m] + s * b_step) * 4u : WF_OOB);
     }
   };
-  auto store_a = [&](int st, const f32x4& v) {
-    if (tid < 360) *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst) = v;
+  auto store_a = [&](int st, const f32x4 (&v)[2]) {
+    *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[0]) = v[0];
+    if (a_dst[1] >= 0) *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[1]) = v[1];
   };
-  auto store_b = [&](int st, const f32x4 (&v)[4]) {
+  auto store_b = [&](int st, const f32x4 (&v)[WF_BQ]) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(Bs + st * WF_BSTAGE + b_dst[m]) = v[m];
+    for (int m = 0; m < WF_BQ; ++m) *reinterpret_cast<f32x4*>(Bs + st * WF_BSTAGE + b_dst[m]) = v[m];
   };
 
   // ---- fragment addresses (K-step invariant) -------------------------------------------------------------------------
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
   int fb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int row = (4 * wi + j) * 64 + kg * 32 + li;
+    const int row = (4 * wi + j) * WF_KB + li;
     fb[j] = row * 8 + ((lh ^ ((row >> 3) & 1)) << 2);
   }
 
@@ -312,24 +325,24 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // Register-side prefetch ring of TWO stages: the loads of step s + 3 are issued during step s and written to LDS during
-  // step s + 2, i.e. they have two full K steps (~4000 cycles) to land.  With one block per CU nothing else hides an HBM
-  // miss on the activation patch (a new 128-byte line per pixel every fourth step); with a one-stage ring the kernel sat at
-  // 43 % of the MFMA rate (profiles/r03_b_wino_bench.csv).  The K loop is unrolled by two so that the ring is indexed
-  // statically; an odd trailing step multiplies zeros (past-the-end loads return 0).
-  f32x4 ra0, ra1, rb0[4], rb1[4];
+  // step s + 2, i.e. they have two full K steps to land (a new 128-byte line per patch pixel is touched every fourth
+  // step and misses to HBM).  The K loop is unrolled by two so that the ring is indexed statically; an odd trailing step
+  // multiplies zeros (past-the-end loads return 0).
+  f32x4 ra0[2], ra1[2], rb0[WF_BQ], rb1[WF_BQ];
   {
-    f32x4 a0 = load_a(0), b0[4];
+    f32x4 a0[2], b0[WF_BQ];
+    load_a(0, a0);
     load_b(0, b0);
-    ra0 = load_a(1);
+    load_a(1, ra0);
     load_b(1, rb0);
-    ra1 = load_a(2);
+    load_a(2, ra1);
     load_b(2, rb1);
     store_a(0, a0);
     store_b(0, b0);
   }
   __syncthreads();
 
-  auto kstep = [&](int rd, f32x4& ra, f32x4 (&rb)[4], int s_next) {
+  auto kstep = [&](int rd, f32x4 (&ra)[2], f32x4 (&rb)[WF_BQ], int s_next) {
     const float* as = As + rd * WF_ASTAGE;
     const float* bs = Bs + rd * WF_BSTAGE;
     f32x4 d1[4], d2[4], bf[4];
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
     WF_SB();
-    ra = load_a(s_next);
+    load_a(s_next, ra);
     load_b(s_next, rb);
     __syncthreads();
   };
@@ -374,19 +387,19 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
 
   // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------
   // columns (in registers): P[i][0] = M[i][0] + M[i][1] + M[i][2],  P[i][1] = M[i][1] - M[i][2] - M[i][3]
-  float* Ps = smem;   // [i 4][b 2][tile 32][ko 64]
+  float* Ps = smem;   // [i 4][b 2][tile 32][ko 32]
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
     const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
     const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
-    Ps[((wi * 2 + 0) * 32 + tile) * 64 + kg * 32 + li] = p0;
-    Ps[((wi * 2 + 1) * 32 + tile) * 64 + kg * 32 + li] = p1;
+    Ps[((wi * 2 + 0) * 32 + tile) * WF_KB + li] = p0;
+    Ps[((wi * 2 + 1) * 32 + tile) * WF_KB + li] = p1;
   }
   __syncthreads();
   // rows (through LDS): y[0][b] = P[0][b] + P[1][b] + P[2][b],  y[1][b] = P[1][b] - P[2][b] - P[3][b]
   {
-    const int tile = tid >> 4, kq = (tid & 15) * 4;
+    const int tile = tid >> 3, kq = (tid & 7) * 4;
     const int ty = 4 * pyb + (tile >> 3), tx = 8 * pxb + (tile & 7);
     const int ko = k0 + kq;
     if (ko < p.Ko) {
@@ -394,12 +407,14 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) P[i][b] = *reinterpret_cast<const f32x4*>(Ps + ((i * 2 + b) * 32 + tile) * 64 + kq);
+        for (int b = 0; b < 2; ++b) P[i][b] = *reinterpret_cast<const f32x4*>(Ps + ((i * 2 + b) * 32 + tile) * WF_KB + kq);
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = (ko + q < p.nbias) ? p.bias[ko + q] : 0.f;
       }
+      // the convolutions that reach this kernel fuse no activation, ReLU or LeakyReLU only (ops.conv2d): one select
+      const float slope = p.act == SO_ACT_RELU ? 0.f : (p.act == SO_ACT_LEAKY ? p.act_param : 1.f);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int h = 2 * ty + a;
@@ -408,10 +423,8 @@ __global__ __launch_bounds__(512, 2) void wino_fused_k(const WinoP p) {
           const int w = 2 * tx + b;
           if (h < p.H && w < p.W) {
             f32x4 v = (a == 0 ? P[0][b] + P[1][b] + P[2][b] : P[1][b] - P[2][b] - P[3][b]) + bv;
-            if (p.act != SO_ACT_NONE) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = so_actf(p.act, v[q], p.act_param);
-            }
+            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * slope;   // none / ReLU / LeakyReLU
             const long long off = ((long long)(n * p.H + h) * p.W + w) * p.ldy + ko;
             if (p.gate) {
               const f32x4 g = ld4(p.gate + off);
@@ -498,6 +511,7 @@ int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, 
   const int th = (H + 1) / 2, tw = (W + 1) / 2;
   const long long T = (long long)Nb * th * tw;
   if (T <= 0 || T >= (1 << 24) || so_wino_ws_floats(Nb, H, W, C, Ko) * 4 > wino_ws_bytes) return SO_ERR_SHAPE;
+  if (act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   float* V = wino_ws;
   float* Mx = wino_ws + 16 * T * C;
@@ -534,6 +548,7 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
       (gate && (((uintptr_t)gate) & 15)))
     return SO_ERR_ALIGN;
+  if (act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY) return SO_ERR_SHAPE;
   const long long xb = (long long)Nb * H * W * ldx * 4, ub = so_wino_fused_weight_floats(Ko, C, 0) * 4;
   if (xb <= 0 || xb >= 0x7FFFFFF0LL || ub >= 0x7FFFFFF0LL) return SO_ERR_SHAPE;
   WinoP p = {};
@@ -553,7 +568,12 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino_fused_k, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, p);
+  // live timing (bench.py roofline): key "fprop, tile slot 7" = the fused Winograd kernel; FLOPs = what the MATRIX PIPE
+  // executes (16 transform points x tiles incl. patch padding x Ko x C x 2), i.e. 1 / 2.25 of the direct convolution's
+  const double tiles = (double)Nb * p.pbx * p.pby * 32.0;
+  const int slot = so_prof_begin(0 * 8 + 7, 2.0 * 16.0 * tiles * (double)Ko * (double)C, (int)tiles, Ko, C, (hipStream_t)stream);
+  hipLaunchKernelGGL(wino_fused_k, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  so_prof_end(slot, (hipStream_t)stream);
   return SO_LAUNCH_CHECK();
 }
 

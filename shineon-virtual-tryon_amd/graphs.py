@@ -12,7 +12,7 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, sample_batch, warmup=2, alias_keys=()):
+    def __init__(self, model, optimizer, sample_batch, warmup=2, alias_keys=(), exchange=None):
         """alias_keys: batch entries used in place (not cloned), e.g. a tensor that is itself the static output of
         another captured graph (the warped cloth handed from the warp stage to the try-on stage)."""
         self.model, self.optimizer = model, optimizer
@@ -20,6 +20,9 @@ class GraphedTrainStep:
                              for k, v in sample_batch.items()}
         self.alias_keys = tuple(alias_keys)
         self.result = None
+        # trainer.BucketedExchange: its counter bump and "bucket ready" signal kernels are recorded INSIDE the graph, at the
+        # points of the backward pass where each gradient bucket is complete
+        self.exchange = exchange
         optimizer.zero_grad()  # plants the flat gradient views before anything is recorded
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -34,8 +37,12 @@ class GraphedTrainStep:
 
     def _step(self):
         self.optimizer.zero_grad()
+        if self.exchange is not None:
+            self.exchange.begin()
         res = self.model.training_step(self.static_batch, 0)
         res.minimize.backward()
+        if self.exchange is not None:
+            self.exchange.end()
         # keep only detached values: a live autograd graph would pin the parameters' AccumulateGrad nodes to the
         # stream of an earlier iteration and break the capture that follows
         res.minimize = res.minimize.detach()
@@ -57,6 +64,8 @@ class GraphedTrainStep:
         if batch is not None:
             self.load_batch(batch)
         self.graph.replay()
+        if self.exchange is not None:
+            self.exchange.note_replay()
         return self.result
 
 

@@ -40,6 +40,19 @@ def _stream():
 
 _LANE_BASE = [0]
 
+# trainer.BucketedExchange installs a callback here while a backward pass is issued (eagerly or under stream capture): every
+# operator that has just launched the kernels producing a parameter's gradient reports that parameter, so the exchange of a
+# gradient bucket can start as soon as the backward pass has produced it (DDP's "bucket ready" hooks).
+_GRAD_READY = [None]
+
+
+def grad_ready(*params):
+    cb = _GRAD_READY[0]
+    if cb is not None:
+        for q in params:
+            if q is not None:
+                cb(q)
+
 
 class workspace_lane:
     """Context manager: kernels issued inside use their own scratch slabs (lane offset), so that two branches of work
@@ -459,6 +472,7 @@ class _Conv2dFn(torch.autograd.Function):
             fork.join()
         elif need_w or need_b:
             dw, db = weight_grads(lane=0)
+        grad_ready(w_direct, b_direct)   # both the input- and the weight-gradient kernels of this layer are in the stream
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -733,6 +747,8 @@ class _NormFn(torch.autograd.Function):
             ),
             "norm_bwd",
         )
+        if ctx.direct is not None:
+            grad_ready(*ctx.direct)
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -811,6 +827,7 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
         ctx.save_for_backward(x, qkv, a, o, gamma)
         ctx.params = (wq, bq, gamma)  # first tensors of the adjacent weight / bias runs, and gamma
+        ctx.ready = (wq, bq, wk, bk, wv, bv, gamma)
         return out
 
     @staticmethod
@@ -847,6 +864,7 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         _gemm(1, 0, E, c, b * n, dqkv.data_ptr(), E, 0, x.data_ptr(), _ld(x), 0, wg, c, 0, 1, res=wg, ldres=c, device=dev)
         wsb = workspace(dev, L.so_colsum_ws_floats(b * n, E) * 4, lane=2)
         check(L.so_colsum(dqkv.data_ptr(), E, b * n, E, bq.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
+        grad_ready(*ctx.ready)
         return dx, None, None, None, None, None, None, None
 
 
@@ -939,6 +957,7 @@ class _SelfAttentionFn(torch.autograd.Function):
                 _gemm(1, 0, rows_, c, b * n, g_.data_ptr(), ldg_, 0, xp, ldx, 0, wg, c, 0, 1, res=wg, ldres=c, device=dev)
                 wsb = workspace(dev, L.so_colsum_ws_floats(b * n, rows_) * 4, lane=2)
                 check(L.so_colsum(g_.data_ptr(), ldg_, b * n, rows_, bpar.grad.data_ptr(), 1, wsb.data_ptr(), _stream()), "colsum")
+            grad_ready(*direct)
             return dx, None, None, None, None, None, None, None
         dwq, dwk, dwv = f(d, c), f(d, c), f(c, c)
         _gemm(1, 0, d, c, b * n, dq.data_ptr(), d, 0, xp, ldx, 0, dwq.data_ptr(), c, 0, 1, device=dev)
@@ -1415,14 +1434,14 @@ def _wino_mode(ci, co, n, h, w):
     if WINOGRAD in ("fused", "nonfused"):
         return WINOGRAD
     tw, th = (w + 1) // 2, (h + 1) // 2
-    blocks = n * ((tw + 7) // 8) * ((th + 3) // 4) * ((co + 63) // 64)   # fused kernel: one block per (8x4-tile patch, 64 ko)
+    blocks = n * ((tw + 7) // 8) * ((th + 3) // 4) * ((co + 31) // 32)   # fused kernel: one block per (8x4-tile patch, 32 ko)
     # measured (profiles/r03_wino_bench.csv): the fused kernel wins while the transformed operands of the non-fused form
     # (16 / 4 x the activation size, written and read once each) outweigh its better GEMM: up to 128 channels from 64x48x4
     # pixels, up to 256 channels from 64x48x8 pixels; the deep layers (256..512 channels at <= 32x24) go to the 16-GEMM batch
     px, cmin = n * h * w, min(ci, co)
-    if blocks >= 256 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
+    if blocks >= 512 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
         return "fused"
-    return "nonfused" if cmin >= 128 else ("fused" if blocks >= 256 else "direct")
+    return "nonfused" if cmin >= 128 else ("fused" if blocks >= 512 else "direct")
 
 
 def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):

@@ -4,7 +4,7 @@ ops.py: torch supplies device memory, the current stream and the autograd tape; 
 import torch
 
 from ._lib import check, lib
-from .ops import (ACT_CODES, ACT_NONE, _direct_grad_ok, _ld, _require_cuda, _stream, nhwc_empty, to_rows, workspace)
+from .ops import (ACT_CODES, ACT_NONE, _direct_grad_ok, _ld, _require_cuda, _stream, grad_ready, nhwc_empty, to_rows, workspace)
 
 GAN_MODES = {"original": 0, "ls": 1, "w": 2, "hinge": 3}
 
@@ -216,6 +216,7 @@ class _StackConvParamsFn(torch.autograd.Function):
                 outs.append(None)
             else:
                 outs.append(bpart)
+            grad_ready(pw, pb)
         return tuple(outs)
 
 
@@ -285,6 +286,7 @@ class _SpectralNormFn(torch.autograd.Function):
         if ctx.direct is not None:
             check(L.so_spectral_norm_bwd(g.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), o, i, r * s,
                                          ctx.direct.grad.data_ptr(), 1, ws.data_ptr(), _stream()), "spectral_norm_bwd")
+            grad_ready(ctx.direct)
             return None, None, None, None
         dw = torch.empty((o, r, s, i), dtype=torch.float32, device=w.device)
         check(L.so_spectral_norm_bwd(g.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), o, i, r * s,

@@ -93,6 +93,32 @@ class HipAdam(torch.optim.Optimizer):
         """Gradients stay views of the flat slab; one fill kernel clears them."""
         ops.fill_(self.flat_grads, 0.0)
 
+    def slot_table(self):
+        """[(parameter, slab offset, padded size in floats)] in slab order (trainer.BucketedExchange cuts buckets from it)."""
+        if self._flat is None:
+            self._build()
+        offs = [off for _, off, _, _ in self._slots] + [self._flat[0].numel()]
+        return [(p, off, offs[i + 1] - off) for i, (p, off, _, _) in enumerate(self._slots)]
+
+    @torch.no_grad()
+    def begin_step(self):
+        """Advance the step counter once; the caller then applies the update piecewise with step_range()."""
+        if self._flat is None:
+            self._build()
+        if not torch.cuda.is_current_stream_capturing():
+            self.check_slabs()
+        self._steps += 1
+
+    @torch.no_grad()
+    def step_range(self, lo, hi, grad_scale=1.0):
+        """Adam on the slab range [lo, hi) with the step number set by begin_step(): element-wise, so any partition of the
+        slab gives bit-identical parameters to one step() over the whole of it."""
+        flat_p, flat_g, m, v = self._flat
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        ops.adam_step(flat_p[lo:hi], flat_g[lo:hi], m[lo:hi], v[lo:hi], float(group["lr"]), b1, b2, group["eps"], self._steps,
+                      grad_scale)
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None

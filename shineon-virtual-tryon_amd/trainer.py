@@ -89,6 +89,164 @@ class GradientAllReducer:
         return self.finish()
 
 
+class BucketedExchange:
+    """Gradient exchange OVERLAPPED WITH THE BACKWARD PASS of a single model (what torch DDP does for the reference,
+    train.py:52-57,76-85), also when forward + backward replay as one hipGraph.
+
+    The optimizer's flat gradient slab is cut at parameter boundaries into buckets of ~`bucket_bytes` (xGMI is point-to-point:
+    ring collectives are per-link bound, so buckets are sized in bytes - 64 MB by default - not a fixed count).  The backward
+    pass produces the slab from its END (last layers first).  While it is being issued - eagerly or under stream capture -
+    every operator reports the parameters whose gradient kernels it has just launched (ops.grad_ready, plus autograd's
+    post-accumulate hooks for gradients that go through AccumulateGrad); when all parameters of a bucket have reported as
+    often as in the calibration pass, a one-thread kernel stores the step counter into that bucket's signal word
+    (so_signal_store: a node of the graph when capturing).  After launching the step the host queues, per bucket in readiness
+    order, on the communication stream:  hipStreamWaitValue32(word >= step)  ->  all-reduce of the bucket  ->  Adam on the
+    bucket's slab range.  The exchange and the update of the last layers thus run while the backward pass of the earlier
+    layers is still executing; nothing here synchronises the host.
+
+    Safety: a bucket's parameters are read for the last time by the input-gradient kernels launched before its signal node
+    (same stream), its gradients are written for the last time there too; buckets are disjoint slab ranges.  finish() makes
+    the compute stream wait for the communication stream before the next forward."""
+
+    def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
+        from ._lib import check, lib
+
+        self.opt, self.group = optimizer, group
+        self.L, self._check = lib(), check
+        if not self.L.so_signal_can_wait():
+            raise RuntimeError("this device does not support hipStreamWaitValue32; use GradientAllReducer")
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        table = optimizer.slot_table()
+        total = optimizer.flat_grads.numel()
+        want = max(1, int(bucket_bytes) // 4)
+        n_b = max(2, min(len(table), (total + want - 1) // want))   # at least two, so that something can overlap
+        per = (total + n_b - 1) // n_b
+        self.buckets = []   # [lo, hi, parameters] in slab order
+        lo, members = 0, []
+        for p, off, size in table:
+            members.append(p)
+            if off + size - lo >= per and len(self.buckets) < n_b - 1:
+                self.buckets.append([lo, off + size, members])
+                lo, members = off + size, []
+        if members:
+            self.buckets.append([lo, total, members])
+        self.bucket_of = {id(p): b for b, (_, _, ps) in enumerate(self.buckets) for p in ps}
+        self.flags = [self.L.so_signal_alloc() for _ in self.buckets]
+        if not all(self.flags):
+            raise RuntimeError("hipExtMallocWithFlags(hipMallocSignalMemory) failed")
+        self.counter = torch.zeros(2, dtype=torch.int32, device=optimizer.flat_grads.device)
+        self.comm = torch.cuda.Stream()
+        self.expected = None        # {id(param): reports per backward pass}, from the calibration pass
+        self.order = None           # bucket indices in the order they became ready in the calibration pass
+        self._count, self._signalled, self._calib_order = {}, set(), []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p, _, _ in table]
+        self.step_no = 0
+        self._launched = False
+        self._armed = False
+
+    def __del__(self):
+        try:
+            for f in self.flags:
+                self.L.so_signal_free(f)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---- while the backward pass is being issued ---------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def begin(self):
+        """Call right before forward + backward are issued (inside the capture when capturing): bumps the device-side step
+        counter and arms the readiness hooks."""
+        from . import ops
+
+        self._check(self.L.so_counter_bump(self.counter.data_ptr(), self._stream()), "counter_bump")
+        if not torch.cuda.is_current_stream_capturing():
+            self.step_no += 1           # the device counter advances when the bump EXECUTES: now, or at every graph replay
+        self._count, self._signalled, self._calib_order = {}, set(), []
+        ops._GRAD_READY[0] = self._on_ready
+        self._armed = True
+
+    def _on_ready(self, p):
+        b = self.bucket_of.get(id(p))
+        if b is None or not self._armed:   # (the autograd hooks also fire in backward passes this engine does not drive)
+            return
+        self._count[id(p)] = self._count.get(id(p), 0) + 1
+        if self.expected is None or b in self._signalled:
+            if self.expected is None and (not self._calib_order or self._calib_order[-1] != b):
+                self._calib_order.append(b)
+            return
+        if all(self._count.get(id(q), 0) >= self.expected.get(id(q), 0) for q in self.buckets[b][2]):
+            self._signal(b)
+
+    def _signal(self, b):
+        self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), self._stream()), "signal_store")
+        self._signalled.add(b)
+
+    def end(self):
+        """Call right after backward has been issued: buckets that did not complete through the hooks (parameters without a
+        gradient this step) are signalled here, i.e. at the end of the backward pass."""
+        from . import ops
+
+        ops._GRAD_READY[0] = None
+        self._armed = False
+        if self.expected is None:       # calibration pass: remember how often each parameter reports and the bucket order
+            self.expected = dict(self._count)
+            seen, order = set(), []
+            for b in reversed(self._calib_order):   # a bucket is ready at its LAST report
+                if b not in seen:
+                    seen.add(b)
+                    order.append(b)
+            order.reverse()
+            self.order = order + [b for b in range(len(self.buckets)) if b not in seen]
+        for b in range(len(self.buckets)):
+            if b not in self._signalled:
+                self._signal(b)
+
+    def note_replay(self):
+        """A captured step (with begin() / end() recorded inside) has just been replayed."""
+        self.step_no += 1
+
+    # ---- after the step has been launched ----------------------------------------------------------------------------
+    def launch(self, grad_scale_extra=1.0):
+        """Queue wait -> all-reduce -> Adam per bucket on the communication stream.  Non-blocking for the host with RCCL."""
+        self.opt.begin_step()
+        scale = grad_scale_extra / self.world
+        flat = self.opt.flat_grads
+        for b in self.order:
+            lo, hi, _ = self.buckets[b]
+            self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, self.comm.cuda_stream), "stream_wait_ge")
+            with torch.cuda.stream(self.comm):
+                if self.world > 1:
+                    dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+                self.opt.step_range(lo, hi, grad_scale=scale)
+        self._launched = True
+
+    def finish(self):
+        """The compute stream waits for every bucket's update (call before the next forward / a checkpoint)."""
+        if self._launched:
+            torch.cuda.current_stream().wait_stream(self.comm)
+            self._launched = False
+
+    def describe(self):
+        sizes = [(hi - lo) * 4 / 1e6 for lo, hi, _ in self.buckets]
+        return f"{len(self.buckets)} buckets of " + "/".join(f"{x:.0f}" for x in sizes) + " MB, exchange overlapped with backward"
+
+
+def _make_exchange(optimizer, bucketed, bucket_bytes):
+    env = os.environ.get("SHINEON_BUCKETED")
+    use = (_world() > 1) if bucketed is None else bool(bucketed)
+    if env is not None and bucketed is None:
+        use = env == "1"
+    if not use:
+        return None
+    try:
+        return BucketedExchange(optimizer, bucket_bytes)
+    except RuntimeError as e:   # no hipStreamWaitValue32 on this device: the whole-slab exchange after the graph
+        logger.warning("bucketed gradient exchange unavailable (%s); falling back to GradientAllReducer", e)
+        return None
+
+
 # ---- buffers / parameters: ONE collective each ------------------------------------------------------------------------
 def flatten_float_buffers(model):
     """Re-home every floating-point buffer of `model` (BatchNorm running_mean / running_var) as a view of ONE flat tensor
@@ -164,7 +322,10 @@ def _to_device(batch, device):
 class TrainStep:
     """One optimisation step of one model: (load batch ->) forward + backward -> gradient exchange -> Adam."""
 
-    def __init__(self, model, optimizer, sample_batch, graph=True, overlap=True, accumulate=1, sync_buffers=True):
+    def __init__(self, model, optimizer, sample_batch, graph=True, overlap=True, accumulate=1, sync_buffers=True,
+                 bucketed=None, bucket_bytes=64 << 20):
+        """bucketed: exchange + update per gradient bucket while the backward pass is still running (BucketedExchange);
+        None = when there is more than one rank (SHINEON_BUCKETED=1 / 0 forces it on / off, e.g. single-rank tests)."""
         self.model, self.optimizer = model, optimizer
         self.accumulate = max(1, int(accumulate))
         self.graph = bool(graph) and self.accumulate == 1   # gradient accumulation re-enters backward: eager only
@@ -172,6 +333,7 @@ class TrainStep:
         self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(model) is not None
         optimizer.zero_grad()
         self.reducer = GradientAllReducer(optimizer.flat_grads)
+        self.exchange = _make_exchange(optimizer, bucketed, bucket_bytes) if self.accumulate == 1 else None
         self._pending = False
         self._micro = 0
         self._graphed = None
@@ -181,7 +343,7 @@ class TrainStep:
 
             snap = _BufferSnapshot(model)
             self._eager(sample_batch, update=False)  # measures igemm plans, sizes every scratch slab before the capture
-            self._graphed = GraphedTrainStep(model, optimizer, sample_batch)
+            self._graphed = GraphedTrainStep(model, optimizer, sample_batch, exchange=self.exchange)
             torch.cuda.synchronize()
             snap.restore()
 
@@ -191,12 +353,16 @@ class TrainStep:
     def _eager(self, batch, update=True):
         if self._micro == 0:
             self.optimizer.zero_grad()
+        if self.exchange is not None:
+            self.exchange.begin()
         res = self.model.training_step(batch, 0)
         (res.minimize / self.accumulate if self.accumulate > 1 else res.minimize).backward()
+        if self.exchange is not None:
+            self.exchange.end()
         self._micro += 1
         if update and self._micro == self.accumulate:
             self._micro = 0
-            self.reducer.start()
+            self._start_exchange()
             self._pending = True
             if not self.overlap:
                 self.flush()
@@ -204,10 +370,19 @@ class TrainStep:
             self._micro = 0
         return res
 
+    def _start_exchange(self):
+        if self.exchange is not None:
+            self.exchange.launch()      # per bucket on the communication stream: wait for its signal, all-reduce, Adam
+        else:
+            self.reducer.start()
+
     def flush(self):
         """Complete the outstanding gradient exchange and apply Adam (no-op if nothing is pending)."""
         if self._pending:
-            self.optimizer.step(grad_scale=self.reducer.finish())
+            if self.exchange is not None:
+                self.exchange.finish()
+            else:
+                self.optimizer.step(grad_scale=self.reducer.finish())
             self._pending = False
 
     @property
@@ -221,7 +396,7 @@ class TrainStep:
             broadcast_buffers(self.model)
         if self._graphed is not None and self._fits(batch):
             res = self._graphed(batch)
-            self.reducer.start()
+            self._start_exchange()
             self._pending = True
             if not self.overlap:
                 self.flush()
@@ -380,7 +555,8 @@ class MultiOptimizerStep:
     optimizer step, zero_grad.  Runs eagerly: the generator pass is five dependent forward passes whose launch count
     dwarfs a hipGraph's benefit only at toy sizes."""
 
-    def __init__(self, model, optimizers, networks=None, accumulate=1, sync_buffers=True):
+    def __init__(self, model, optimizers, networks=None, accumulate=1, sync_buffers=True, bucketed=None,
+                 bucket_bytes=64 << 20):
         self.model, self.optimizers = model, list(optimizers)
         # Lightning's DDP wrapper re-broadcasts rank 0's buffers before EVERY forward (broadcast_buffers=True), i.e. once
         # per optimizer_idx: the per-process "syncbatch" running statistics of every SPADE stay rank 0's on all ranks
@@ -395,6 +571,12 @@ class MultiOptimizerStep:
         self._own = [[p for p in net.parameters()] for net in self.networks]
         flats = [o.flat_grads for o in self.optimizers]  # builds the slabs now: backward then accumulates straight into them
         self.reducers = [GradientAllReducer(f) for f in flats] if _world() > 1 else None
+        # per optimizer: bucketed exchange overlapped with that optimizer's own backward pass (the update must have landed
+        # before the next optimizer's forward, which reads the freshly updated network - Lightning's order)
+        self.exchanges = None
+        if self.accumulate == 1:
+            ex = [_make_exchange(o, bucketed, bucket_bytes) for o in self.optimizers]
+            self.exchanges = ex if all(e is not None for e in ex) else None
         self.stepped = False
 
     def _only(self, idx):
@@ -416,9 +598,17 @@ class MultiOptimizerStep:
             self._only(idx)
             if self.sync_buffers:
                 broadcast_buffers(self.model)
+            ex = self.exchanges[idx] if self.exchanges is not None else None
+            if ex is not None:
+                ex.begin()
             result = self.model.training_step(batch, batch_idx, idx)
             result.minimize.sum().backward()
-            if update:
+            if ex is not None:
+                ex.end()
+                ex.launch()
+                ex.finish()
+                opt.zero_grad()
+            elif update:
                 scale = self.reducers[idx].all_reduce() if self.reducers is not None else 1.0
                 opt.step(grad_scale=scale / self.accumulate)
                 opt.zero_grad()

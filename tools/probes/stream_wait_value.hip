@@ -27,8 +27,14 @@ int main() {
   CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
   printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
   unsigned* flag = nullptr;
-  CK(hipExtMallocWithFlags((void**)&flag, 64, hipMallocSignalMemory));
-  CK(hipMemset(flag, 0, 64));
+  hipError_t fe = hipExtMallocWithFlags((void**)&flag, 8, hipMallocSignalMemory);   // signal memory: exactly 8 bytes
+  printf("hipExtMallocWithFlags(8, hipMallocSignalMemory) -> %s\n", hipGetErrorString(fe));
+  if (fe != hipSuccess) {
+    fe = hipHostMalloc((void**)&flag, 64, hipHostMallocCoherent | hipHostMallocMapped);   // fine-grained host memory
+    printf("hipHostMalloc(coherent) -> %s\n", hipGetErrorString(fe));
+    if (fe != hipSuccess) return 1;
+  }
+  CK(hipMemset(flag, 0, 8));
   unsigned* step = nullptr;
   CK(hipMalloc(&step, 4));
   CK(hipMemset(step, 0, 4));
