@@ -249,15 +249,16 @@ int so_axpby(const float* x, float a, float* y, float b, long long n, void* stre
 /* ---- stream hand-off inside a replayed hipGraph (trainer.BucketedExchange; reference: torch DDP's bucketed all-reduce
  * overlapped with backward, train.py:76-85).  so_signal_alloc: one 8-byte signal word (hipMallocSignalMemory; the one
  * allocation this library makes - signal memory has no torch equivalent), returned as an integer device address, 0 on failure;
- * so_counter_bump: counter[0] += 1 (first node of the captured step); so_signal_store: flag[0] = counter[0] with system-scope
- * release ("everything in front of me in this stream is done"); so_stream_wait_ge: host call, makes `stream` wait until
- * flag[0] >= value (hipStreamWaitValue32: no compute unit is occupied); so_signal_can_wait: 1 if the device supports it. */
+ * so_counter_bump: counter[0] += 1 (first node of the captured step); so_signal_store: flag[0] = counter[0] with a release at
+ * system scope (system_scope = 1, for the mode-0 waiter) or agent scope ("everything in front of me in this stream is done"); so_stream_wait_ge: host call, makes `stream` wait until
+ * flag[0] >= value (mode 0: hipStreamWaitValue32, no compute unit occupied; mode 1: a one-lane polling kernel with s_sleep,
+ * which keeps the command processor out of it); so_signal_can_wait: 1 if the device supports mode 0. */
 long long so_signal_alloc(void);
 int so_signal_free(long long ptr);
 int so_signal_can_wait(void);
 int so_counter_bump(void* counter, void* stream);
-int so_signal_store(void* flag, const void* counter, void* stream);
-int so_stream_wait_ge(void* flag, int value, void* stream);
+int so_signal_store(void* flag, const void* counter, int system_scope, void* stream);
+int so_stream_wait_ge(void* flag, int value, int mode, void* stream);
 
 /* ---- geometric matching + attention row kernels (csrc/gmm.hip) ------------------------------------ */
 

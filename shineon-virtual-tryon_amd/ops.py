@@ -107,6 +107,10 @@ VGG_SPLIT_BF16 = os.environ.get("SHINEON_VGG_SPLIT_BF16", "0") == "1"
 #   "auto"     per layer from the measured crossover (tools/wino_bench.py)
 #   "0"        direct implicit GEMM everywhere
 WINOGRAD = os.environ.get("SHINEON_WINOGRAD", "auto")
+# Trainable weights must be re-transformed every call (100 bytes of traffic per (ko, c) filter): on the 768-pixel layers
+# (GMM 3x3 at 16x12, U-Net u4 / u5) that costs what the transform saves - kernel trace r03_h: 17 weight transforms per step =
+# 0.29 ms.  Winograd for trainable convolutions therefore starts at 3072 pixels (32x24 at bs = 4).
+WINOGRAD_TRAINABLE_MIN_PIXELS = int(os.environ.get("SHINEON_WINOGRAD_TRAINABLE_MIN_PIXELS", "3072"))
 
 
 
@@ -337,9 +341,10 @@ class _Conv2dFn(torch.autograd.Function):
         wo = (wd + 2 * pad - s) // stride + 1
         y = nhwc_empty(n, ho, wo, op, x.device)
         ws = workspace(x.device)
-        wino = _wino_mode(cp, op, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1) else "direct"
+        wino = _wino_mode(cp, op, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1 and
+                                                  n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
         if wino != "direct":
-            # 3x3 / s1 / p1 (U-Net up path, GMM, SPADE): Winograd F(2x2,3x3); trainable weights are transformed per call
+            # 3x3 / s1 / p1 (U-Net up path, SPADE): Winograd F(2x2,3x3); trainable weights are transformed per call
             u = _wino_weights(w, None, False, fused=wino == "fused", ko_pad=op)
             wino_conv3x3(xr.data_ptr(), _ld(xr), u, bias, None, y.data_ptr(), op, n, h, wd, cp, op, act, x.device,
                          fused=wino == "fused", act_param=act_param)
@@ -446,7 +451,8 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
-            wino = _wino_mode(op, cp, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1) else "direct"
+            wino = _wino_mode(op, cp, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1 and
+                                                      n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
             if wino != "direct":
                 # the input gradient of a 3x3 / s1 / p1 convolution = the same convolution with flipped taps, C <-> Ko
                 u = _wino_weights(w, None, True, fused=wino == "fused", ko_pad=op)

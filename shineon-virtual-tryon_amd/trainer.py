@@ -119,7 +119,8 @@ class BucketedExchange:
         table = optimizer.slot_table()
         total = optimizer.flat_grads.numel()
         want = max(1, int(bucket_bytes) // 4)
-        n_b = max(2, min(len(table), (total + want - 1) // want))   # at least two, so that something can overlap
+        n_min = int(os.environ.get("SHINEON_BUCKETS_MIN", "2"))     # at least two, so that something can overlap
+        n_b = max(n_min, min(len(table), (total + want - 1) // want))
         per = (total + n_b - 1) // n_b
         self.buckets = []   # [lo, hi, parameters] in slab order
         lo, members = 0, []
@@ -143,6 +144,9 @@ class BucketedExchange:
         self.step_no = 0
         self._launched = False
         self._armed = False
+        # 1 = one-lane polling kernel (default), 0 = hipStreamWaitValue32: the command-processor wait slows the dispatch of
+        # every kernel of the step it waits through (6.64 vs 5.87 ms/step measured on c3), the polling kernel does not
+        self.wait_mode = int(os.environ.get("SHINEON_WAIT_MODE", "1"))
 
     def __del__(self):
         try:
@@ -180,7 +184,8 @@ class BucketedExchange:
             self._signal(b)
 
     def _signal(self, b):
-        self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), self._stream()), "signal_store")
+        self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), int(self.wait_mode == 0), self._stream()),
+                    "signal_store")
         self._signalled.add(b)
 
     def end(self):
@@ -215,7 +220,7 @@ class BucketedExchange:
         flat = self.opt.flat_grads
         for b in self.order:
             lo, hi, _ = self.buckets[b]
-            self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, self.comm.cuda_stream), "stream_wait_ge")
+            self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, self.wait_mode, self.comm.cuda_stream), "stream_wait_ge")
             with torch.cuda.stream(self.comm):
                 if self.world > 1:
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
@@ -240,6 +245,8 @@ def _make_exchange(optimizer, bucketed, bucket_bytes):
         use = env == "1"
     if not use:
         return None
+    if os.environ.get("SHINEON_BUCKET_MB"):
+        bucket_bytes = int(float(os.environ["SHINEON_BUCKET_MB"]) * (1 << 20))
     try:
         return BucketedExchange(optimizer, bucket_bytes)
     except RuntimeError as e:   # no hipStreamWaitValue32 on this device: the whole-slab exchange after the graph

@@ -87,7 +87,7 @@ def test_unet_mask_model_vs_reference_golden(cuda, variant):
     # element-wise against the reference's own gradients (every 97th element of all 52 tensors); the kinked variants
     # (ReLU / LeakyReLU, esp. with attention) move by a few percent when one pre-activation changes side of its kink -
     # the oracle itself is 3.9e-2 from the reference there (tests/test_oracle_golden.py)
-    rel = {"plain": 1e-2, "gelu": 5e-3, "attn": 8e-2, "attn_gelu": 5e-3}[variant]
+    rel = {"plain": 5e-2, "gelu": 5e-3, "attn": 8e-2, "attn_gelu": 5e-3}[variant]
     assert_grad_samples(lambda k: params[k].grad, g, "gs97:", rel=rel, what=f"{variant} vs reference", floor=4e-5 if "attn" in variant else 2e-7)
 
 
