@@ -505,13 +505,21 @@ def main():
         engine = TrainStep(model, opt, batch, graph=not args.no_graph, overlap=True)
         step, flush = (lambda: engine(batch)), engine.flush
         launch = "eager" if args.no_graph else "one hipGraph (forward+backward); Adam and all-reduce eager"
+        if engine.exchange is not None:
+            launch += "; " + engine.exchange.describe()
         eager_step = lambda: (engine.flush(), engine._eager(batch), engine.flush())  # noqa: E731
         join = lambda: (engine.flush(), torch.cuda.synchronize())  # noqa: E731
     log(f"{L.so_igemm_plan_count()} igemm plans in use")
     if world > 1:
-        log(f"rank {rank}/{world}: backend {dist.get_backend()}, NCCL_ALGO={os.environ.get('NCCL_ALGO', 'default')}, "
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else "-"
+        except Exception:  # noqa: BLE001
+            rccl = "?"
+        how = (engine.exchange.describe() if cfg != "c4" and engine.exchange is not None else "4 buckets each, started after the graph")
+        log(f"rank {rank}/{world}: backend {dist.get_backend()} (RCCL {rccl}), NCCL_ALGO={os.environ.get('NCCL_ALGO', 'default')}, "
+            f"NCCL_PROTO={os.environ.get('NCCL_PROTO', 'default')} (set NCCL_DEBUG=INFO for RCCL's own ring / tree report), "
             f"gradient slabs " + ", ".join(f"{o.flat_grads.numel() * 4 / 1e6:.1f} MB" for o in
-                                           ([engine.optw, engine.optu] if cfg == "c4" else [opt])) + " in 4 buckets each")
+                                           ([engine.optw, engine.optu] if cfg == "c4" else [opt])) + f": {how}")
 
     log(f"rank {rank}/{world}: models built, warm-up {args.warmup} steps")
     for i in range(args.warmup):
@@ -551,10 +559,30 @@ def main():
             eager_step()
         fence()
         L.so_prof_enable(0)
+    exposed_ms = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # What the gradient exchange costs on this node: the SAME steps once more with the collectives switched off (after
+        # the timed region; the ranks' weights diverge from here on, only the clock is read).  exposed = with - without.
+        reducers = [engine.redw, engine.redu] if cfg == "c4" else [engine.exchange if engine.exchange is not None else engine.reducer]
+        for r_ in reducers:
+            r_.world = 1
+        for _ in range(2):
+            step()
+        flush()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        flush()
+        fence()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = max(0.0, 1e3 * (elapsed - float(t.item())) / args.steps)
+        log(f"gradient exchange exposed: {exposed_ms:.3f} ms/step ({1e3 * elapsed / args.steps:.3f} with, "
+            f"{1e3 * float(t.item()) / args.steps:.3f} without collectives)")
 
     ms = (ctypes.c_float * 32)()
     fl = (ctypes.c_float * 32)()
@@ -592,7 +620,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[cfg], "config": cfg, "launch": launch, "batch_per_gpu": args.batch,
                        "global_batch": world * args.batch, "frames_per_sample": nfr, "parallelism": f"dp{world}",
-                       "step_api": "shineon_virtual_tryon_amd.trainer." + ("ChainedTrainStep" if cfg == "c4" else "TrainStep")},
+                       "step_api": "shineon_virtual_tryon_amd.trainer." + ("ChainedTrainStep" if cfg == "c4" else "TrainStep"),
+                       "exchange_exposed_ms": exposed_ms,
+                       "exchange": (None if world == 1 else
+                                    (engine.exchange.describe() if cfg != "c4" and getattr(engine, "exchange", None) is not None
+                                     else "flat slab in 4 buckets after the graph, hidden behind the other model's graph")),
+                       "pipeline_gain_ms": getattr(engine, "pipeline_gain_ms", None) if cfg == "c4" else None,
+                       "exchange_probe_ms": getattr(engine, "exchange_ms", None) if cfg == "c4" else None},
             "roofline": {
                 "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,

@@ -213,14 +213,22 @@ __device__ __forceinline__ f32x4 wf_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 
 constexpr int WF_KB = 32;                  // output channels per block
 constexpr int WF_NT = 256;                 // threads per block
-constexpr int WF_APIX = 12;                // floats per pixel slot in the raw A stage (8 data + 4 pad)
-constexpr int WF_AROW = 24;                // pixel slots per patch row
-constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 2880 floats = 11.25 KB
+#ifndef WF_BLOCKS_PER_CU
+#define WF_BLOCKS_PER_CU 3                  // = waves per SIMD: caps the kernel at 168 VGPRs
+#endif
+// Raw A stage, compact form: 8 floats per pixel slot, 20 slots per patch row, and the two channel quads of a pixel swapped
+// on odd row slots (physical quad = q ^ (row slot & 1)).  Bank quad of a lane's read = (2 * slot + quad) mod 16: the
+// stride-2 tile walk gives tx = 0..7 -> the 8 even quads, a tile row adds 2 * 20 = 8 (mod 16) and flips the parity, so the
+// hardware's 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} cover all 16 quads once (same property as the padded
+// 12-float / 24-slot layout of the first version, in 6.25 KB instead of 11.25 KB: 44.5 KB per block, three blocks per CU).
+constexpr int WF_APIX = 8;                 // floats per pixel slot in the raw A stage
+constexpr int WF_AROW = 20;                // pixel slots per patch row
+constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 1600 floats = 6.25 KB
 constexpr int WF_BSTAGE = 16 * WF_KB * 8;           // 4096 floats = 16 KB
-constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 54.5 KB; the epilogue re-uses the first 32 KB
+constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 44.5 KB; the epilogue re-uses the first 32 KB
 constexpr int WF_BQ = 16 * WF_KB * 2 / WF_NT;       // B quads per thread per step (4)
 
-__global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
+__global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const WinoP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * WF_ASTAGE;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
       const int h = h_org + ppy, w = w_org + ppx;
       if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) a_src[m] = ((n * p.H + h) * p.W + w) * p.ldx + aq * 4;
       const int rs = (ppy >> 1) + (ppy & 1) * 5, cs = (ppx >> 1) + (ppx & 1) * 9;
-      a_dst[m] = (rs * WF_AROW + cs) * WF_APIX + aq * 4;
+      a_dst[m] = (rs * WF_AROW + cs) * WF_APIX + ((aq ^ (rs & 1)) << 2);
     }
   }
   // B: 1024 quads per step = 4 per thread: quad id = tid + 256 m -> row = xi * 32 + ko_local, quad = id & 1
@@ -308,8 +316,9 @@ __global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int cs = ttx + (b >> 1) + (b & 1) * 9;
-    fa1[b] = ((tty + (a1 >> 1) + (a1 & 1) * 5) * WF_AROW + cs) * WF_APIX + lh * 4;
-    fa2[b] = ((tty + (a2 >> 1) + (a2 & 1) * 5) * WF_AROW + cs) * WF_APIX + lh * 4;
+    const int r1 = tty + (a1 >> 1) + (a1 & 1) * 5, r2 = tty + (a2 >> 1) + (a2 & 1) * 5;
+    fa1[b] = (r1 * WF_AROW + cs) * WF_APIX + ((lh ^ (r1 & 1)) << 2);
+    fa2[b] = (r2 * WF_AROW + cs) * WF_APIX + ((lh ^ (r2 & 1)) << 2);
   }
   int fb[4];
 #pragma unroll
@@ -324,24 +333,14 @@ __global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // Register-side prefetch ring of TWO stages: the loads of step s + 3 are issued during step s and written to LDS during
-  // step s + 2, i.e. they have two full K steps to land (a new 128-byte line per patch pixel is touched every fourth
-  // step and misses to HBM).  The K loop is unrolled by two so that the ring is indexed statically; an odd trailing step
-  // multiplies zeros (past-the-end loads return 0).
-  f32x4 ra0[2], ra1[2], rb0[WF_BQ], rb1[WF_BQ];
-  {
-    f32x4 a0[2], b0[WF_BQ];
-    load_a(0, a0);
-    load_b(0, b0);
-    load_a(1, ra0);
-    load_b(1, rb0);
-    load_a(2, ra1);
-    load_b(2, rb1);
-    store_a(0, a0);
-    store_b(0, b0);
-  }
-  __syncthreads();
-
+  // Register-side prefetch.  WF_RING = 2: two stages in flight (the loads of step s + 3 are issued during step s and written
+  // to LDS during step s + 2; K loop unrolled by two so the ring is indexed statically) - needed while ONE or TWO blocks
+  // shared a CU.  WF_RING = 1 (default with three blocks per CU): one stage (issued at the end of step s, written during
+  // step s + 1); the other two blocks of the CU cover the latency and the kernel fits 168 VGPRs without spilling.
+  // Past-the-end loads return 0, so trailing steps need no branches.
+#ifndef WF_RING
+#define WF_RING 1
+#endif
   auto kstep = [&](int rd, f32x4 (&ra)[2], f32x4 (&rb)[WF_BQ], int s_next) {
     const float* as = As + rd * WF_ASTAGE;
     const float* bs = Bs + rd * WF_BSTAGE;
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
     WF_SB();
-    store_a(rd ^ 1, ra);     // the stage consumed by the NEXT step (its loads were issued two steps ago)
+    store_a(rd ^ 1, ra);     // the stage consumed by the NEXT step
     store_b(rd ^ 1, rb);
     WF_SB();
 #pragma unroll
@@ -380,10 +379,42 @@ __global__ __launch_bounds__(WF_NT, 2) void wino_fused_k(const WinoP p) {
     load_b(s_next, rb);
     __syncthreads();
   };
+#if WF_RING == 2
+  f32x4 ra0[2], ra1[2], rb0[WF_BQ], rb1[WF_BQ];
+  {
+    f32x4 a0[2], b0[WF_BQ];
+    load_a(0, a0);
+    load_b(0, b0);
+    load_a(1, ra0);
+    load_b(1, rb0);
+    load_a(2, ra1);
+    load_b(2, rb1);
+    store_a(0, a0);
+    store_b(0, b0);
+  }
+  __syncthreads();
   for (int s = 0; s < p.nks; s += 2) {
     kstep(0, ra0, rb0, s + 3);
     kstep(1, ra1, rb1, s + 4);
   }
+#else
+  f32x4 ra0[2], rb0[WF_BQ];
+  {
+    f32x4 a0[2], b0[WF_BQ];
+    load_a(0, a0);
+    load_b(0, b0);
+    load_a(1, ra0);
+    load_b(1, rb0);
+    store_a(0, a0);
+    store_b(0, b0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < p.nks; ++s) {
+    kstep(cur, ra0, rb0, s + 2);
+    cur ^= 1;
+  }
+#endif
 
   // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------
   // columns (in registers): P[i][0] = M[i][0] + M[i][1] + M[i][2],  P[i][1] = M[i][1] - M[i][2] - M[i][3]

@@ -1445,9 +1445,9 @@ def _wino_mode(ci, co, n, h, w):
     # (16 / 4 x the activation size, written and read once each) outweigh its better GEMM: up to 128 channels from 64x48x4
     # pixels, up to 256 channels from 64x48x8 pixels; the deep layers (256..512 channels at <= 32x24) go to the 16-GEMM batch
     px, cmin = n * h * w, min(ci, co)
-    if blocks >= 512 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
+    if blocks >= 768 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
         return "fused"
-    return "nonfused" if cmin >= 128 else ("fused" if blocks >= 512 else "direct")
+    return "nonfused" if cmin >= 128 else ("fused" if blocks >= 768 else "direct")
 
 
 def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):

@@ -425,7 +425,9 @@ class ChainedTrainStep:
     schedule = "auto": "pipeline" on one rank; with several ranks the try-on exchange is timed once on this node and
         "pipeline" is kept only if it is cheaper than what the two-stream schedule gains (`pipeline_gain_ms`)."""
 
-    def __init__(self, warp, optw, unet, optu, sample_batch, schedule="auto", pipeline_gain_ms=1.0, sync_buffers=True, log=None):
+    def __init__(self, warp, optw, unet, optu, sample_batch, schedule="auto", pipeline_gain_ms=None, sync_buffers=True, log=None):
+        """pipeline_gain_ms: what the two-stream schedule saves per step on ONE rank; None = measure it here (both schedules
+        are built and replayed a few times without optimizer steps, MAX over ranks) when the choice has to be made."""
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
         self.batch = sample_batch
         optw.zero_grad()
@@ -434,34 +436,88 @@ class ChainedTrainStep:
         self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(warp) is not None
         self._pending_u = False
         self._gp = self._gw = self._gu = None
-        self.exchange_ms = None
+        self.exchange_ms = self.pipeline_gain_ms = None
+        auto = schedule == "auto" and _world() > 1
         if schedule == "auto":
             schedule = "pipeline"
-            if _world() > 1:
-                self.exchange_ms = self._time_exchange(optu.flat_grads)
-                schedule = "pipeline" if self.exchange_ms < pipeline_gain_ms else "sequential"
-                if log:
-                    log(f"try-on gradient all-reduce ({optu.flat_grads.numel() * 4 / 1e6:.1f} MB, {_world()} ranks): "
-                        f"{self.exchange_ms:.2f} ms -> {schedule} schedule")
         self.schedule = schedule
         snap = _BufferSnapshot(warp, unet)
         if schedule != "eager":
             self.eager_step(sample_batch, update=False)  # plans measured, scratch slabs sized, gradient views planted
-        if schedule == "pipeline":
-            from .graphs import GraphedChainedStep
-
-            self._gp = GraphedChainedStep(warp, optw, unet, optu, sample_batch)
-        elif schedule == "sequential":
-            from .graphs import GraphedTrainStep
-
-            self._gw = GraphedTrainStep(warp, optw, sample_batch)
-            b2 = dict(sample_batch)
-            b2["cloth"] = warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
-            self._gu = GraphedTrainStep(unet, optu, b2, alias_keys=("cloth",))
+        if auto:
+            # with several ranks the try-on exchange has no other graph to hide behind in the two-stream schedule: keep that
+            # schedule only if what it gains on this node (measured, not assumed) exceeds what the exchange costs (measured)
+            self.exchange_ms = self._time_exchange(optu.flat_grads)
+            self._build("pipeline", sample_batch)
+            t_pipe = self._time_graphs()
+            if pipeline_gain_ms is None:
+                self._build("sequential", sample_batch)
+                t_seq = self._time_graphs(sequential=True)
+                pipeline_gain_ms = self._max_over_ranks(t_seq - t_pipe)
+            self.pipeline_gain_ms = pipeline_gain_ms
+            self.schedule = "pipeline" if self.exchange_ms < pipeline_gain_ms else "sequential"
+            if self.schedule == "sequential":
+                self._gp = None
+                if self._gw is None:
+                    self._build("sequential", sample_batch)
+            else:
+                self._gw = self._gu = None
+            if log:
+                log(f"try-on gradient all-reduce ({optu.flat_grads.numel() * 4 / 1e6:.1f} MB, {_world()} ranks): "
+                    f"{self.exchange_ms:.2f} ms exposed in the two-stream schedule, which gains {pipeline_gain_ms:.2f} ms/step "
+                    f"on one rank -> {self.schedule} schedule")
+        elif schedule in ("pipeline", "sequential"):
+            self._build(schedule, sample_batch)
         elif schedule != "eager":
             raise ValueError(f"unknown schedule {schedule!r}")
         torch.cuda.synchronize()
         snap.restore()
+
+    def _build(self, schedule, sample_batch):
+        if schedule == "pipeline":
+            from .graphs import GraphedChainedStep
+
+            self._gp = GraphedChainedStep(self.warp, self.optw, self.unet, self.optu, sample_batch)
+        else:
+            from .graphs import GraphedTrainStep
+
+            self._gw = GraphedTrainStep(self.warp, self.optw, sample_batch)
+            b2 = dict(sample_batch)
+            b2["cloth"] = self.warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
+            self._gu = GraphedTrainStep(self.unet, self.optu, b2, alias_keys=("cloth",))
+
+    @staticmethod
+    def _max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if _world() > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def _time_graphs(self, sequential=False, reps=5):
+        """ms per step of the captured graphs alone (no exchange, no optimizer step: the gradients are simply overwritten)."""
+        def once():
+            if sequential:
+                self._gw()
+                self._gu()
+            else:
+                self._gp.launch_warp_forward()
+                self._gp.launch_tryon()
+                self._gp.launch_warp_backward()
+
+        for _ in range(2):
+            once()
+        if not sequential:
+            self._gp.join()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            once()
+        if not sequential:
+            self._gp.join()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
     @staticmethod
     def _time_exchange(flat, reps=5):
