@@ -40,9 +40,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
-KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = executed MFMA FLOPs (direct-convolution FLOPs / 2.25)
+KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = algorithmic (direct-convolution) FLOPs; executed = / 2.25
+WINOGRAD_KEY, WINOGRAD_FACTOR = 7, 2.25
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
-GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": None}  # None: the MFMA launches' own 2MNK sum
+GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": 3131.4}  # None: the MFMA launches' own 2MNK sum
+# sams: 62 627 GF per bs = 4 x 5-frame step = the sum of 2MNK over every MFMA launch of the step as DIRECT convolutions
+# (profiles/r02_sams_bench_bs4.json; 15 657 GF at bs = 1: linear in the batch).  Since round 3 part of the 3x3 convolutions
+# run as Winograd F(2x2,3x3) and execute fewer FLOPs; the algorithmic figure stays the direct-convolution one.
 WORKLOADS = {
     "c4": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then UnetMaskModel "
           "(self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, 256x192",
@@ -102,13 +106,25 @@ def sams_cpu_baseline(batch_size):
             opts[idx].step()
 
     step()
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
-    return {"value": batch_size * 2 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
-            "sample": f"1 warm-up + 1 timed three-optimizer SamsModel step of the oracle at 256x192, bs={batch_size}, reduced to "
-                      f"n_frames_total=2 (2 instead of 5 generator passes per generation; bounded CPU time), PyTorch CPU fp32: "
-                      f"{dt:.1f} s/step"}
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    dt = times[1]
+    return {"value": batch_size * 2 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(),
+            "kind": "port (bounded sample)",
+            "sample": f"1 warm-up + 3 timed three-optimizer SamsModel steps of the oracle at 256x192, bs={batch_size}, BOUNDED to "
+                      f"n_frames_total=2 (2 instead of 5 generator passes per generation: the full step would take minutes), "
+                      f"PyTorch CPU fp32: median {dt:.1f} s/step (min {times[0]:.1f}, max {times[2]:.1f})"}
+
+
+def sams_traffic(key):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    return json.load(open(tpath)).get("sams", {}).get(key, {}).get("hbm_bytes_per_launch")
 
 
 def sams_hbm_table(dev, batch_size):
@@ -231,7 +247,7 @@ def run_sams(args, trainer, L):
     dom = max(range(32), key=lambda k: ms[k])
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     step_ms = 1e3 * elapsed / args.steps
-    gf_step = sum(fl) / args.steps / 1e9
+    gf_step = GF_PER_FRAME["sams"] * args.batch * nfr
     mfma_ms = sum(ms) / args.steps
     out = {
         "metric": "SAMS-GAN video frames/sec (three-optimizer step, fwd+bwd+Adam) at 256x192, n_frames=5",
@@ -245,11 +261,13 @@ def run_sams(args, trainer, L):
                    "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         "roofline": {
             "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": sams_traffic(KEY_NAMES[dom]),
+            "traffic_source": "profiles/traffic.json [sams]: PMC passes of a bounded slice (--batch 1 --steps 1), bytes per launch",
             "timing": "hip events, eager launches in the timed region", "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
             "step": {"algorithmic_gflop_per_step": gf_step, "achieved": gf_step / step_ms,
                      "frac": gf_step / step_ms / PEAK_FP32_MFMA_TFLOPS,
-                     "note": "2MNK of every MFMA launch of the step / measured step time / fp32-MFMA peak"},
+                     "note": "direct-convolution FLOPs of the step (sum of 2MNK over its MFMA launches before Winograd, "
+                             "profiles/r02_sams_bench_bs4.json) / measured step time / fp32-MFMA peak"},
             "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / step_ms,
             "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
         },
@@ -596,9 +614,14 @@ def main():
         dom = max(range(32), key=lambda k: ms[k])
         traffic = None  # HBM bytes per launch of the dominant instantiation, from the committed PMC passes
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and cfg == "c4":
-            traffic = json.load(open(tpath)).get(KEY_NAMES[dom], {}).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(cfg, {}).get(KEY_NAMES[dom], {}).get("hbm_bytes_per_launch")
         achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+        executed = achieved / WINOGRAD_FACTOR if dom == WINOGRAD_KEY else achieved
+        for k_ in kernels.values():
+            k_["executed_tflops"] = k_["tflops"]
+        if "winograd_fused" in kernels:
+            kernels["winograd_fused"]["executed_tflops"] = kernels["winograd_fused"]["tflops"] / WINOGRAD_FACTOR
         mfma_ms = sum(ms) / prof_steps
         step_ms = 1e3 * elapsed / args.steps
         gf_step = GF_PER_FRAME[cfg] * args.batch if GF_PER_FRAME[cfg] else sum(fl) / prof_steps / 1e9
@@ -628,8 +651,14 @@ def main():
                        "pipeline_gain_ms": getattr(engine, "pipeline_gain_ms", None) if cfg == "c4" else None,
                        "exchange_probe_ms": getattr(engine, "exchange_ms", None) if cfg == "c4" else None},
             "roofline": {
-                "bound": "mfma", "kernel": f"so_igemm_kernel<{KEY_NAMES[dom]}>", "achieved": achieved,
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "bound": "mfma",
+                "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else
+                           f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
+                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "achieved_note": ("ALGORITHMIC FLOPs of the convolutions (2 x pixels x Ko x 9C, SURVEY 8d) / kernel time; "
+                                  "Winograd F(2x2,3x3) needs 1/2.25 of those multiplications, so this may exceed the peak of a "
+                                  "direct kernel - executed_* is what the matrix pipe actually does") if dom == WINOGRAD_KEY else None,
+                "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                   "bytes per launch)" if traffic else None,
@@ -643,6 +672,8 @@ def main():
                                  "measured step time / fp32-MFMA peak"},
                 "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / step_ms,
                 "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
+                "all_mfma_executed_tflops": (sum(fl) - fl[WINOGRAD_KEY] * (1 - 1 / WINOGRAD_FACTOR)) / (sum(ms) * 1e-3) / 1e12
+                if sum(ms) > 0 else 0.0,
             },
             "kernels": kernels,
         }

@@ -599,10 +599,11 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  // live timing (bench.py roofline): key "fprop, tile slot 7" = the fused Winograd kernel; FLOPs = what the MATRIX PIPE
-  // executes (16 transform points x tiles incl. patch padding x Ko x C x 2), i.e. 1 / 2.25 of the direct convolution's
-  const double tiles = (double)Nb * p.pbx * p.pby * 32.0;
-  const int slot = so_prof_begin(0 * 8 + 7, 2.0 * 16.0 * tiles * (double)Ko * (double)C, (int)tiles, Ko, C, (hipStream_t)stream);
+  // live timing (bench.py roofline): key "fprop, tile slot 7" = the fused Winograd kernel.  FLOPs recorded = the ALGORITHMIC
+  // FLOPs of the convolution it computes (2 * pixels * Ko * 9C, SURVEY 8d's unit); the matrix pipe executes 1 / 2.25 of them
+  // (16 instead of 36 multiplications per 2x2 tile and channel pair) - bench.py reports both.
+  const int slot = so_prof_begin(0 * 8 + 7, 2.0 * (double)Nb * H * W * (double)Ko * 9.0 * (double)C, Nb * H * W, Ko, 9 * C,
+                                 (hipStream_t)stream);
   hipLaunchKernelGGL(wino_fused_k, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);
   return SO_LAUNCH_CHECK();
