@@ -211,11 +211,7 @@ __device__ __forceinline__ f32x4 wf_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return r;
 }
 
-constexpr int WF_KB = 32;                  // output channels per block
 constexpr int WF_NT = 256;                 // threads per block
-#ifndef WF_BLOCKS_PER_CU
-#define WF_BLOCKS_PER_CU 3                  // = waves per SIMD: caps the kernel at 168 VGPRs
-#endif
 // Raw A stage, compact form: 8 floats per pixel slot, 20 slots per patch row, and the two channel quads of a pixel swapped
 // on odd row slots (physical quad = q ^ (row slot & 1)).  Bank quad of a lane's read = (2 * slot + quad) mod 16: the
 // stride-2 tile walk gives tx = 0..7 -> the 8 even quads, a tile row adds 2 * 20 = 8 (mod 16) and flips the parity, so the
@@ -224,11 +220,15 @@ constexpr int WF_NT = 256;                 // threads per block
 constexpr int WF_APIX = 8;                 // floats per pixel slot in the raw A stage
 constexpr int WF_AROW = 20;                // pixel slots per patch row
 constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 1600 floats = 6.25 KB
-constexpr int WF_BSTAGE = 16 * WF_KB * 8;           // 4096 floats = 16 KB
-constexpr int WF_LDS_FLOATS = 2 * (WF_ASTAGE + WF_BSTAGE);   // 44.5 KB; the epilogue re-uses the first 32 KB
-constexpr int WF_BQ = 16 * WF_KB * 2 / WF_NT;       // B quads per thread per step (4)
-
-__global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const WinoP p) {
+// NKG = 32-channel output groups per wave (output channels per block KB = 32 * NKG):
+//   NKG = 1: 16 MFMAs per wave and K step, 44.5 KB LDS, <= 168 VGPRs, THREE blocks per CU;
+//   NKG = 2: the four A fragments of a lane's tile (8 LDS reads + 32 VALU of input transform) feed 32 MFMAs instead of 16,
+//            76.5 KB LDS, <= 256 VGPRs, TWO blocks per CU - for Ko >= 64.
+template <int NKG>
+__global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const WinoP p) {
+  constexpr int WF_KB = 32 * NKG;
+  constexpr int WF_BSTAGE = 16 * WF_KB * 8;
+  constexpr int WF_BQ = 16 * WF_KB * 2 / WF_NT;       // B quads per thread per step (4 or 8)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * WF_ASTAGE;
@@ -270,16 +270,14 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
       a_dst[m] = (rs * WF_AROW + cs) * WF_APIX + ((aq ^ (rs & 1)) << 2);
     }
   }
-  // B: 1024 quads per step = 4 per thread: quad id = tid + 256 m -> row = xi * 32 + ko_local, quad = id & 1
-  int b_src[WF_BQ], b_dst[WF_BQ];
-#pragma unroll
-  for (int m = 0; m < WF_BQ; ++m) {
-    const int qid = tid + WF_NT * m;
-    const int row = qid >> 1, q = qid & 1;
-    const int xi = row / WF_KB, kol = row % WF_KB;
-    b_src[m] = (k0 + kol < p.Ko) ? (xi * p.Ko + k0 + kol) * 8 + q * 4 : -1;
-    b_dst[m] = row * 8 + ((q ^ ((row >> 3) & 1)) << 2);
-  }
+  // B: 16 * KB * 2 quads per step, WF_BQ per thread: quad id = tid + 256 m -> row = (tid >> 1) + 128 m = xi * KB + ko_local.
+  // 128 rows further = 128 / KB transform points further at the same ko_local (and the same swizzle bit): one base each.
+  const int b_row0 = tid >> 1, b_q = tid & 1;
+  const int b_kol = b_row0 % WF_KB;
+  const bool b_ok = k0 + b_kol < p.Ko;
+  const int b_src0 = ((b_row0 / WF_KB) * p.Ko + k0 + b_kol) * 8 + b_q * 4;
+  const int b_src_m = (128 / WF_KB) * p.Ko * 8;                 // per m
+  const int b_dst0 = b_row0 * 8 + ((b_q ^ ((b_row0 >> 3) & 1)) << 2);
   const int b_step = 16 * p.Ko * 8;   // floats per K step in U
 
   auto load_a = [&](int s, f32x4 (&dst)[2]) {
@@ -291,19 +289,19 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
     }
   };
   auto load_b = [&](int s, f32x4 (&dst)[WF_BQ]) {
+    const bool ok = b_ok & (s < p.nks);
+    const int base = b_src0 + s * b_step;
 #pragma unroll
-    for (int m = 0; m < WF_BQ; ++m) {
-      const bool ok = (b_src[m] >= 0) & (s < p.nks);
-      dst[m] = wf_bload(rU, ok ? (unsigned)(b_src[m] + s * b_step) * 4u : WF_OOB);
-    }
+    for (int m = 0; m < WF_BQ; ++m) dst[m] = wf_bload(rU, ok ? (unsigned)(base + m * b_src_m) * 4u : WF_OOB);
   };
   auto store_a = [&](int st, const f32x4 (&v)[2]) {
     *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[0]) = v[0];
     if (a_dst[1] >= 0) *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[1]) = v[1];
   };
   auto store_b = [&](int st, const f32x4 (&v)[WF_BQ]) {
+    float* dst = Bs + st * WF_BSTAGE + b_dst0;
 #pragma unroll
-    for (int m = 0; m < WF_BQ; ++m) *reinterpret_cast<f32x4*>(Bs + st * WF_BSTAGE + b_dst[m]) = v[m];
+    for (int m = 0; m < WF_BQ; ++m) *reinterpret_cast<f32x4*>(dst + m * 128 * 8) = v[m];
   };
 
   // ---- fragment addresses (K-step invariant) -------------------------------------------------------------------------
@@ -312,26 +310,21 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
   const int a2 = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
   const float sgn = wi == 1 ? 1.f : -1.f;
   const int ttx = li & 7, tty = li >> 3;
-  int fa1[4], fa2[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int cs = ttx + (b >> 1) + (b & 1) * 9;
-    const int r1 = tty + (a1 >> 1) + (a1 & 1) * 5, r2 = tty + (a2 >> 1) + (a2 & 1) * 5;
-    fa1[b] = (r1 * WF_AROW + cs) * WF_APIX + ((lh ^ (r1 & 1)) << 2);
-    fa2[b] = (r2 * WF_AROW + cs) * WF_APIX + ((lh ^ (r2 & 1)) << 2);
-  }
-  int fb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = (4 * wi + j) * WF_KB + li;
-    fb[j] = row * 8 + ((lh ^ ((row >> 3) & 1)) << 2);
-  }
+  // all fragment addresses are ONE base per operand row plus compile-time offsets (ds_read immediates): patch column b adds
+  // ((b >> 1) + (b & 1) * 9) slots; transform point j adds j * KB rows and group g 32 rows of B (neither changes the swizzle)
+  const int r1 = tty + (a1 >> 1) + (a1 & 1) * 5, r2 = tty + (a2 >> 1) + (a2 & 1) * 5;
+  const int fa1_0 = (r1 * WF_AROW + ttx) * WF_APIX + ((lh ^ (r1 & 1)) << 2);
+  const int fa2_0 = (r2 * WF_AROW + ttx) * WF_APIX + ((lh ^ (r2 & 1)) << 2);
+  const int fb_row0 = 4 * wi * WF_KB + li;
+  const int fb_0 = fb_row0 * 8 + ((lh ^ ((li >> 3) & 1)) << 2);
 
-  f32x16 acc[4];
+  f32x16 acc[NKG][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int g = 0; g < NKG; ++g)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][j][r] = 0.f;
 
   // Register-side prefetch.  WF_RING = 2: two stages in flight (the loads of step s + 3 are issued during step s and written
   // to LDS during step s + 2; K loop unrolled by two so the ring is indexed statically) - needed while ONE or TWO blocks
@@ -344,14 +337,16 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
   auto kstep = [&](int rd, f32x4 (&ra)[2], f32x4 (&rb)[WF_BQ], int s_next) {
     const float* as = As + rd * WF_ASTAGE;
     const float* bs = Bs + rd * WF_BSTAGE;
-    f32x4 d1[4], d2[4], bf[4];
+    f32x4 d1[4], d2[4], bf[NKG][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      d1[b] = *reinterpret_cast<const f32x4*>(as + fa1[b]);
-      d2[b] = *reinterpret_cast<const f32x4*>(as + fa2[b]);
+      d1[b] = *reinterpret_cast<const f32x4*>(as + fa1_0 + ((b >> 1) + (b & 1) * 9) * WF_APIX);
+      d2[b] = *reinterpret_cast<const f32x4*>(as + fa2_0 + ((b >> 1) + (b & 1) * 9) * WF_APIX);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + fb[j]);
+    for (int g = 0; g < NKG; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[g][j] = *reinterpret_cast<const f32x4*>(bs + fb_0 + (j * WF_KB + g * 32) * 8);
     WF_SB();
     f32x4 t[4], v[4];
 #pragma unroll
@@ -365,7 +360,9 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
+      for (int g = 0; g < NKG; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[g][j][e], acc[g][j], 0, 0, 0);
     WF_SB();
     store_a(rd ^ 1, ra);     // the stage consumed by the NEXT step
     store_b(rd ^ 1, rb);
@@ -373,7 +370,9 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
 #pragma unroll
     for (int e = 2; e < 4; ++e)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
+      for (int g = 0; g < NKG; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[g][j][e], acc[g][j], 0, 0, 0);
     WF_SB();
     load_a(s_next, ra);
     load_b(s_next, rb);
@@ -418,19 +417,23 @@ __global__ __launch_bounds__(WF_NT, WF_BLOCKS_PER_CU) void wino_fused_k(const Wi
 
   // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------
   // columns (in registers): P[i][0] = M[i][0] + M[i][1] + M[i][2],  P[i][1] = M[i][1] - M[i][2] - M[i][3]
-  float* Ps = smem;   // [i 4][b 2][tile 32][ko 32]
+  float* Ps = smem;   // [i 4][b 2][tile 32][ko KB]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
-    const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
-    Ps[((wi * 2 + 0) * 32 + tile) * WF_KB + li] = p0;
-    Ps[((wi * 2 + 1) * 32 + tile) * WF_KB + li] = p1;
-  }
+  for (int g = 0; g < NKG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float p0 = acc[g][0][r] + acc[g][1][r] + acc[g][2][r];
+      const float p1 = acc[g][1][r] - acc[g][2][r] - acc[g][3][r];
+      Ps[((wi * 2 + 0) * 32 + tile) * WF_KB + g * 32 + li] = p0;
+      Ps[((wi * 2 + 1) * 32 + tile) * WF_KB + g * 32 + li] = p1;
+    }
   __syncthreads();
   // rows (through LDS): y[0][b] = P[0][b] + P[1][b] + P[2][b],  y[1][b] = P[1][b] - P[2][b] - P[3][b]
-  {
-    const int tile = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+  for (int rep = 0; rep < NKG; ++rep) {
+    const int task = tid + WF_NT * rep;                  // (tile, output-channel quad): 32 x (KB / 4) tasks
+    const int tile = task / (WF_KB / 4), kq = (task % (WF_KB / 4)) * 4;
     const int ty = 4 * pyb + (tile >> 3), tx = 8 * pxb + (tile & 7);
     const int ko = k0 + kq;
     if (ko < p.Ko) {
@@ -574,6 +577,11 @@ int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int f
 
 // y = gate(act(conv3x3_s1_p1(x) + bias)) in ONE launch; U from so_wino_fused_weights with (N, K) = (Ko, C) of THIS call
 // (for an input gradient call it with x = dy, C = the convolution's Ko, Ko = its C and the flip_transpose = 1 weights).
+// Output channels per block: 32 (three blocks per CU; the default - measured equal or better on every VGG layer and in the
+// step: 557-558 vs 551 frames/s) or 64 for Ko >= 64 (two blocks per CU, the A fragments feed 32 MFMAs instead of 16).
+static int g_wino_force_nkg1 = 1;
+void so_wino_fused_force_kb32(int on) { g_wino_force_nkg1 = on; }
+
 int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream) {
   if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
@@ -587,15 +595,20 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   p.x_bytes = (unsigned)xb; p.u_bytes = (unsigned)ub;
   p.ldx = ldx; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.C = C; p.Ko = Ko; p.nbias = nbias;
   p.pbx = ((W + 1) / 2 + 7) / 8; p.pby = ((H + 1) / 2 + 3) / 4;
-  p.nkb = (Ko + WF_KB - 1) / WF_KB; p.nks = (C + 7) / 8;
+  const int nkg = (Ko >= 64 && !g_wino_force_nkg1) ? 2 : 1;   // output channels per block: 64 (two groups per wave) or 32
+  const int KB = 32 * nkg;
+  p.nkb = (Ko + KB - 1) / KB; p.nks = (C + 7) / 8;
   p.act = act; p.act_param = act_param;
   const long long blocks = (long long)Nb * p.pbx * p.pby * p.nkb;
   if (blocks <= 0 || blocks > 0x7FFFFFFF) return SO_ERR_SHAPE;
-  constexpr size_t lds = (size_t)WF_LDS_FLOATS * sizeof(float);
+  const size_t lds = (size_t)(2 * (WF_ASTAGE + 16 * KB * 8)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)((2 * (WF_ASTAGE + 16 * 32 * 8)) * sizeof(float)));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2 * (WF_ASTAGE + 16 * 64 * 8)) * sizeof(float)));
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -604,7 +617,10 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   // (16 instead of 36 multiplications per 2x2 tile and channel pair) - bench.py reports both.
   const int slot = so_prof_begin(0 * 8 + 7, 2.0 * (double)Nb * H * W * (double)Ko * 9.0 * (double)C, Nb * H * W, Ko, 9 * C,
                                  (hipStream_t)stream);
-  hipLaunchKernelGGL(wino_fused_k, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  if (nkg == 2)
+    hipLaunchKernelGGL(wino_fused_k<2>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(wino_fused_k<1>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);
   return SO_LAUNCH_CHECK();
 }
