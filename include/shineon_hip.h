@@ -91,6 +91,15 @@ int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, 
                     int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, float* wino_ws,
                     long long wino_ws_bytes, float* ws, long long ws_bytes, void* stream);
 
+/* F(4x4, 3x3), same three-kernel structure with 36 transform points per 4x4 output tile (2.25 multiplications per output
+ * instead of 4, and 2.25x instead of 4x the activation size in transformed operands): the deep VGG19 layers.  Same
+ * argument meaning as so_wino_weights / so_wino_conv3x3; U is [36][Ko][C] (or [36][C][Ko] with flip_transpose = 1). */
+long long so_wino4_ws_floats(int Nb, int H, int W, int C, int Ko);
+int so_wino4_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream);
+int so_wino4_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                     int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, float* wino_ws,
+                     long long wino_ws_bytes, float* ws, long long ws_bytes, void* stream);
+
 /* Fused form: input transform, the 16 GEMMs and the output transform in ONE launch (transformed operands never touch HBM).
  * Weights in the kernel's own order U[ceil(K/8)][16][N][8] with (N, K) = (Ko, C) (flip_transpose = 0) or (C, Ko) built from
  * the flipped taps (flip_transpose = 1: the input gradient, called with x = dy, C <- Ko, Ko <- C).  Same reference call

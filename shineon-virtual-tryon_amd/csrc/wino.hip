@@ -512,6 +512,175 @@ __global__ __launch_bounds__(256) void wino_weights_fused_k(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// F(4x4, 3x3), non-fused: 36 transform points per 4x4 output tile (6x6 input tile) - 2.25 multiplications per output
+// instead of 4 (F(2x2)) or 9 (direct), and only 36/16 = 2.25x the activation size in transformed operands (F(2x2): 4x).
+// Used for the deep VGG layers (>= 256 channels, <= 64x48 pixels), where the 36-GEMM batch fills the chip even at 96 tiles.
+// Interpolation points {0, 1, -1, 2, -1/2, inf}: a search over small rational point sets with this kernel's arithmetic
+// (fp64 transforms, one fp32 rounding of U, V, M; profiles/r03_wino_points.txt) gives 1.7x lower rms and 2.6x lower maximum
+// error than the textbook {0, +-1, +-2, inf} (Lavin & Gray), in line with Barabasz et al. 2018.
+//   B^T rows: (1,3/2,-2,-3/2,1,0) (0,-1,-5/2,-1/2,1,0) (0,1,1/2,-5/2,1,0) (0,-1/2,-1,1/2,1,0) (0,2,-1,-2,1,0) (0,1,3/2,-2,-3/2,1)
+//   G rows  : (1,0,0) (-1/3,-1/3,-1/3) (1/3,-1/3,1/3) (1/15,2/15,4/15) (-16/15,8/15,-4/15) (0,0,1)
+//   A^T rows: (1,1,1,1,1,0) (0,1,-1,2,-1/2,0) (0,1,1,4,1/4,0) (0,1,-1,8,-1/8,1)
+// The transforms themselves run in fp64 (exact for these small-integer combinations of fp32 values) and round ONCE when the
+// transformed operand is stored: V, M and y then carry a single fp32 rounding each instead of the accumulated round-off of
+// two 6-point passes with coefficients up to 8.  The kernels are HBM-bound; the fp64 vector rate is not a limit.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 w4_d(const f32x4& v) { f64x4 r = {(double)v[0], (double)v[1], (double)v[2], (double)v[3]}; return r; }
+__device__ __forceinline__ f32x4 w4_f(const f64x4& v) { f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; return r; }
+
+__device__ __forceinline__ void w4_bt(const f64x4 (&d)[6], f64x4 (&t)[6]) {
+  t[0] = d[0] + 1.5 * (d[1] - d[3]) - 2.0 * d[2] + d[4];
+  t[1] = d[4] - d[1] - 2.5 * d[2] - 0.5 * d[3];
+  t[2] = d[4] + d[1] + 0.5 * d[2] - 2.5 * d[3];
+  t[3] = d[4] - d[2] + 0.5 * (d[3] - d[1]);
+  t[4] = d[4] - d[2] + 2.0 * (d[1] - d[3]);
+  t[5] = d[1] + 1.5 * (d[2] - d[4]) - 2.0 * d[3] + d[5];
+}
+
+// one thread = (tile, channel PAIR-of-pairs): 36 16-byte loads; the 6x6 fp64 intermediate is kept per column pass
+__global__ __launch_bounds__(256) void wino4_input_k(const float* __restrict__ x, int ldx, float* __restrict__ V, int Nb, int H,
+                                                     int W, int C, int th, int tw) {
+  const int cq = C >> 2;
+  const long long T = (long long)Nb * th * tw;
+  const long long total = T * cq;
+  const long long sx = T * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long tile = idx / cq;
+    const int c = (int)(idx - tile * cq) * 4;
+    const int n = (int)(tile / (th * tw));
+    const int rem = (int)(tile - (long long)n * th * tw);
+    const int ty = rem / tw, tx = rem - ty * tw;
+    const int h0 = 4 * ty - 1, w0 = 4 * tx - 1;
+    f64x4 t[6][6];   // t[i][j] = (B^T d)[i][j]: columns first
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f64x4 d[6], o[6];
+      const int w = w0 + j;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int h = h0 + i;
+        const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        d[i] = w4_d(ok ? ld4(x + ((long long)(n * H + h) * W + w) * ldx + c) : z);
+      }
+      w4_bt(d, o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+    }
+    float* out = V + tile * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      f64x4 o[6];
+      w4_bt(t[i], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(out + (i * 6 + j) * sx) = w4_f(o[j]);
+    }
+  }
+}
+
+__device__ __forceinline__ void w4_at(const f64x4 (&m)[6], f64x4 (&y)[4]) {
+  const f64x4 s12 = m[1] + m[2], d12 = m[1] - m[2];
+  y[0] = m[0] + s12 + m[3] + m[4];
+  y[1] = d12 + 2.0 * m[3] - 0.5 * m[4];
+  y[2] = s12 + 4.0 * m[3] + 0.25 * m[4];
+  y[3] = d12 + 8.0 * m[3] - 0.125 * m[4] + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_output_k(const float* __restrict__ Mx, const float* __restrict__ bias, int nbias,
+                                                      const float* __restrict__ gate, float* __restrict__ y, int ldy, int Nb,
+                                                      int H, int W, int Ko, int th, int tw, int act, float act_param) {
+  const int kq = Ko >> 2;
+  const long long T = (long long)Nb * th * tw;
+  const long long total = T * kq;
+  const long long sx = T * Ko;
+  const float slope = act == SO_ACT_RELU ? 0.f : (act == SO_ACT_LEAKY ? act_param : 1.f);
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long tile = idx / kq;
+    const int k = (int)(idx - tile * kq) * 4;
+    const int n = (int)(tile / (th * tw));
+    const int rem = (int)(tile - (long long)n * th * tw);
+    const int ty = rem / tw, tx = rem - ty * tw;
+    const float* src = Mx + tile * Ko + k;
+    f64x4 s[4][6];   // s[a][j] = (A^T M)[a][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f64x4 m[6], o[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m[i] = w4_d(ld4(src + (i * 6 + j) * sx));
+      w4_at(m, o);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s[a][j] = o[a];
+    }
+    f64x4 b = {0.0, 0.0, 0.0, 0.0};
+    if (bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = (k + q < nbias) ? (double)bias[k + q] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int h = 4 * ty + a;
+      f64x4 o[4];
+      w4_at(s[a], o);
+      if (h >= H) continue;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int w = 4 * tx + bb;
+        if (w >= W) continue;
+        f32x4 v = w4_f(o[bb] + b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * slope;
+        const long long off = ((long long)(n * H + h) * W + w) * ldy + k;
+        if (gate) {
+          const f32x4 g = ld4(gate + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = g[q] > 0.f ? v[q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + off) = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_weights_k(const float* __restrict__ w, float* __restrict__ U, int Ko, int C,
+                                                       int Kw, int flip_transpose) {
+  const long long total = (long long)Ko * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int ko = (int)(idx / C), c = (int)(idx - (long long)ko * C);
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int rr = flip_transpose ? 2 - r : r, ss = flip_transpose ? 2 - s : s;
+        g[r][s] = ko < Kw ? w[((long long)ko * 9 + rr * 3 + ss) * C + c] : 0.f;
+      }
+    double t[6][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const double g0 = g[0][s], g1 = g[1][s], g2 = g[2][s];
+      t[0][s] = g0;
+      t[1][s] = -(g0 + g1 + g2) / 3.0;
+      t[2][s] = (g0 - g1 + g2) / 3.0;
+      t[3][s] = (g0 + 2.0 * g1 + 4.0 * g2) / 15.0;
+      t[4][s] = (-16.0 * g0 + 8.0 * g1 - 4.0 * g2) / 15.0;
+      t[5][s] = g2;
+    }
+    const long long sx = (long long)Ko * C;
+    float* out = flip_transpose ? U + (long long)c * Ko + ko : U + (long long)ko * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double g0 = t[i][0], g1 = t[i][1], g2 = t[i][2];
+      out[(i * 6 + 0) * sx] = (float)g0;
+      out[(i * 6 + 1) * sx] = (float)(-(g0 + g1 + g2) / 3.0);
+      out[(i * 6 + 2) * sx] = (float)((g0 - g1 + g2) / 3.0);
+      out[(i * 6 + 3) * sx] = (float)((g0 + 2.0 * g1 + 4.0 * g2) / 15.0);
+      out[(i * 6 + 4) * sx] = (float)((-16.0 * g0 + 8.0 * g1 - 4.0 * g2) / 15.0);
+      out[(i * 6 + 5) * sx] = (float)g2;
+    }
+  }
+}
+
 inline int grid_for(long long n) {
   long long b = (n + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -556,6 +725,44 @@ int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, 
                         0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
   if (err) return err;
   hipLaunchKernelGGL(wino_output_k, dim3(grid_for(T * (Ko >> 2))), dim3(256), 0, st, (const float*)Mx, bias, nbias, gate, y, ldy,
+                     Nb, H, W, Ko, th, tw, act, act_param);
+  return SO_LAUNCH_CHECK();
+}
+
+// ---- F(4x4, 3x3), non-fused ------------------------------------------------------------------------------------------------
+long long so_wino4_ws_floats(int Nb, int H, int W, int C, int Ko) {
+  const long long T = (long long)Nb * ((H + 3) / 4) * ((W + 3) / 4);
+  return 36 * T * ((long long)C + Ko);
+}
+
+// U[36][Ko][C] (flip_transpose = 0) or U'[36][C][Ko] from the flipped taps (input gradient)
+int so_wino4_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream) {
+  if (Ko <= 0 || C <= 0 || Kw > Ko) return SO_ERR_SHAPE;
+  hipLaunchKernelGGL(wino4_weights_k, dim3(grid_for((long long)Ko * C)), dim3(256), 0, (hipStream_t)stream, w, U, Ko, C, Kw,
+                     flip_transpose);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_wino4_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                     int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, float* wino_ws,
+                     long long wino_ws_bytes, float* ws, long long ws_bytes, void* stream) {
+  if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
+      (((uintptr_t)wino_ws) & 15) || (gate && (((uintptr_t)gate) & 15)))
+    return SO_ERR_ALIGN;
+  const int th = (H + 3) / 4, tw = (W + 3) / 4;
+  const long long T = (long long)Nb * th * tw;
+  if (T <= 0 || T >= (1 << 24) || so_wino4_ws_floats(Nb, H, W, C, Ko) * 4 > wino_ws_bytes) return SO_ERR_SHAPE;
+  if (act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY) return SO_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  float* V = wino_ws;
+  float* Mx = wino_ws + 36 * T * C;
+  hipLaunchKernelGGL(wino4_input_k, dim3(grid_for(T * (C >> 2))), dim3(256), 0, st, x, ldx, V, Nb, H, W, C, th, tw);
+  int err = SO_LAUNCH_CHECK();
+  if (err) return err;
+  err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 36, nullptr, nullptr, nullptr,
+                        0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
+  if (err) return err;
+  hipLaunchKernelGGL(wino4_output_k, dim3(grid_for(T * (Ko >> 2))), dim3(256), 0, st, (const float*)Mx, bias, nbias, gate, y, ldy,
                      Nb, H, W, Ko, th, tw, act, act_param);
   return SO_LAUNCH_CHECK();
 }

@@ -107,6 +107,7 @@ VGG_SPLIT_BF16 = os.environ.get("SHINEON_VGG_SPLIT_BF16", "0") == "1"
 #   "auto"     per layer from the measured crossover (tools/wino_bench.py)
 #   "0"        direct implicit GEMM everywhere
 WINOGRAD = os.environ.get("SHINEON_WINOGRAD", "auto")
+WINOGRAD_F44 = os.environ.get("SHINEON_WINOGRAD_F44", "1") != "0"   # F(4x4,3x3) for the deep layers (csrc/wino.hip)
 # Trainable weights must be re-transformed every call (100 bytes of traffic per (ko, c) filter): on the 768-pixel layers
 # (GMM 3x3 at 16x12, U-Net u4 / u5) that costs what the transform saves - kernel trace r03_h: 17 weight transforms per step =
 # 0.29 ms.  Winograd for trainable convolutions therefore starts at 3072 pixels (32x24 at bs = 4).
@@ -345,9 +346,9 @@ class _Conv2dFn(torch.autograd.Function):
                                                   n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
         if wino != "direct":
             # 3x3 / s1 / p1 (U-Net up path, SPADE): Winograd F(2x2,3x3); trainable weights are transformed per call
-            u = _wino_weights(w, None, False, fused=wino == "fused", ko_pad=op)
+            u = _wino_weights(w, None, False, fused=wino == "fused", ko_pad=op, f44=wino == "nonfused4")
             wino_conv3x3(xr.data_ptr(), _ld(xr), u, bias, None, y.data_ptr(), op, n, h, wd, cp, op, act, x.device,
-                         fused=wino == "fused", act_param=act_param)
+                         fused=wino == "fused", act_param=act_param, f44=wino == "nonfused4")
         else:
             check(
                 L.so_conv2d_fprop_padded(
@@ -455,9 +456,9 @@ class _Conv2dFn(torch.autograd.Function):
                                                       n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
             if wino != "direct":
                 # the input gradient of a 3x3 / s1 / p1 convolution = the same convolution with flipped taps, C <-> Ko
-                u = _wino_weights(w, None, True, fused=wino == "fused", ko_pad=op)
+                u = _wino_weights(w, None, True, fused=wino == "fused", ko_pad=op, f44=wino == "nonfused4")
                 wino_conv3x3(dy.data_ptr(), _ld(dy), u, None, None, dxp.data_ptr(), cp, n, h, wd, op, cp, ACT_NONE, dev,
-                             fused=wino == "fused")
+                             fused=wino == "fused", f44=wino == "nonfused4")
             elif DGRAD_IN_PLACE:
                 # trainable weights change every step: read them in place (OHWI rows are contiguous along the GEMM
                 # column c; the engine transposes while staging) instead of writing a transposed copy per step
@@ -1445,12 +1446,14 @@ def _wino_mode(ci, co, n, h, w):
     # (16 / 4 x the activation size, written and read once each) outweigh its better GEMM: up to 128 channels from 64x48x4
     # pixels, up to 256 channels from 64x48x8 pixels; the deep layers (256..512 channels at <= 32x24) go to the 16-GEMM batch
     px, cmin = n * h * w, min(ci, co)
+    if WINOGRAD == "auto" and WINOGRAD_F44 and cmin >= 256 and px <= 24576 and h % 4 == 0 and w % 4 == 0:
+        return "nonfused4"   # F(4x4, 3x3): the deep layers (>= 256 channels at <= 64x48): 2.25 instead of 4 multiplications
     if blocks >= 768 and ((cmin <= 128 and px >= 12288) or (cmin <= 256 and px >= 24576)):
         return "fused"
     return "nonfused" if cmin >= 128 else ("fused" if blocks >= 768 else "direct")
 
 
-def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):
+def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None, f44=False):
     """Winograd-domain weights of the OHWI tensor `wk` (Ko, 3, 3, C): U[16][Ko][C], or for the input gradient U'[16][C][Ko]
     (flipped taps); fused=True: the fused kernel's [K/8][16][N][8] order.  `owner` = (weakref to the parameter, its version): frozen weights are transformed once and cached per
     parameter object and version like the transposed copies; owner None transforms on every call (trainable weights)."""
@@ -1458,16 +1461,16 @@ def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):
     ko = kw if ko_pad is None else ko_pad   # output channels zero-padded to a multiple of 4 (rows >= kw are zero)
     L = lib()
     key = None
-    numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else 16 * ko * c
+    numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else (36 if f44 else 16) * ko * c
     if owner is not None:
         ref, version = owner
         p = ref()
-        key = (id(p), bool(transpose), bool(fused))
+        key = (id(p), bool(transpose), bool(fused), bool(f44))
         hit = _WINO_W_CACHE.get(key) if p is not None else None
         if hit is not None and hit[0]() is p and hit[1] == version and hit[2].numel() == numel:
             return hit[2]
     u = torch.empty(numel, dtype=torch.float32, device=wk.device)
-    fn = L.so_wino_fused_weights if fused else L.so_wino_weights
+    fn = L.so_wino_fused_weights if fused else (L.so_wino4_weights if f44 else L.so_wino_weights)
     check(fn(wk.data_ptr(), u.data_ptr(), ko, kw, c, int(transpose), _stream()), "wino_weights")
     if key is not None and owner[0]() is not None:
         for k in [k for k, v in _WINO_W_CACHE.items() if v[0]() is None]:
@@ -1476,7 +1479,8 @@ def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None):
     return u
 
 
-def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, device, lane=4, fused=False, act_param=0.0):
+def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, device, lane=4, fused=False, act_param=0.0,
+                 f44=False):
     """y = gate(act(conv3x3(x) + bias)) through F(2x2,3x3); u = _wino_weights(...) with N = co rows of K = ci columns."""
     L = lib()
     if fused:
@@ -1484,10 +1488,10 @@ def wino_conv3x3(x_ptr, ldx, u, bias, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act
                                       bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act,
                                       float(act_param), _stream()), "wino_fused_conv3x3")
         return
-    need = L.so_wino_ws_floats(n, h, w, ci, co) * 4
+    need = (L.so_wino4_ws_floats if f44 else L.so_wino_ws_floats)(n, h, w, ci, co) * 4
     wws = workspace(device, need, lane=lane)   # transformed operands: their own slab (split-K slabs live in lane 0)
     ws = workspace(device)
-    check(L.so_wino_conv3x3(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
+    check((L.so_wino4_conv3x3 if f44 else L.so_wino_conv3x3)(x_ptr, ldx, u.data_ptr(), bias.data_ptr() if bias is not None else None,
                             bias.numel() if bias is not None else 0, gate_ptr, y_ptr, ldy, n, h, w, ci, co, act, float(act_param),
                             wws.data_ptr(), wws.numel() * 4, ws.data_ptr(), ws.numel() * 4, _stream()), "wino_conv3x3")
 
@@ -1559,9 +1563,10 @@ class _VggLossFn(torch.autograd.Function):
                                             n2, hh, ww, ci, co, 1, _stream()), "sb16_conv3x3")
                     planes = (oh, om) if emit else None
                 elif _wino_mode(ci, co, n2, hh, ww) != "direct":
-                    fz = _wino_mode(ci, co, n2, hh, ww) == "fused"
-                    wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, wowner, False, fz), bias, None, out.data_ptr(), co, n2, hh, ww,
-                                 ci, co, ACT_RELU, dev, fused=fz)
+                    wm = _wino_mode(ci, co, n2, hh, ww)
+                    fz, f4 = wm == "fused", wm == "nonfused4"
+                    wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, wowner, False, fz, f44=f4), bias, None, out.data_ptr(), co, n2,
+                                 hh, ww, ci, co, ACT_RELU, dev, fused=fz, f44=f4)
                     planes = None
                 else:
                     check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
@@ -1631,9 +1636,10 @@ class _VggLossFn(torch.autograd.Function):
                                         None, None, b, hh, ww, co, ci, 0, _stream()), "sb16_dgrad")
             elif _wino_mode(co, ci, b, hh, ww) != "direct":
                 # input gradient = the same Winograd convolution on flipped taps with C and Ko swapped (U'[16][ci][co])
-                fz = _wino_mode(co, ci, b, hh, ww) == "fused"
-                wino_conv3x3(g.data_ptr(), co, _wino_weights(wk, wkey, True, fz), None, gate, dx.data_ptr(), ci, b, hh, ww, co, ci,
-                             ACT_NONE, dev, fused=fz)
+                wm = _wino_mode(co, ci, b, hh, ww)
+                fz, f4 = wm == "fused", wm == "nonfused4"
+                wino_conv3x3(g.data_ptr(), co, _wino_weights(wk, wkey, True, fz, f44=f4), None, gate, dx.data_ptr(), ci, b, hh, ww, co,
+                             ci, ACT_NONE, dev, fused=fz, f44=f4)
             else:
                 wt = _ihwo(wk, owner=wkey)  # frozen weights: transposed once, reused every step
                 check(L.so_conv2d_dgrad_t_gated(g.data_ptr(), co, wt.data_ptr(), dx.data_ptr(), ci, gate, b, hh, ww, ci, co, 3, 3, 1, 1,
@@ -1673,8 +1679,10 @@ def vgg_target_features(y, cfg, params):
             out = nhwc_empty(n2, hh, ww, co, dev)
             mode = _wino_mode(ci, co, n2, hh, ww)
             if mode != "direct":
-                wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, (weakref.ref(weight), weight._version), False, mode == "fused"),
-                             bias, None, out.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, dev, fused=mode == "fused")
+                wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, (weakref.ref(weight), weight._version), False, mode == "fused",
+                                                               f44=mode == "nonfused4"),
+                             bias, None, out.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, dev, fused=mode == "fused",
+                             f44=mode == "nonfused4")
             else:
                 check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
                                         3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")

@@ -431,6 +431,16 @@ def test_winograd_conv3x3_matches_fp64_convolution(cuda, ops, n, h, w, c, ko, ac
     e_f = float((y2.cpu().double() - ref).abs().max())
     print(f"   fused: max err {e_f:.2e}")
     assert e_f <= 4 * e_d + 2e-6 * big, (e_f, e_d, big)
+    # F(4x4, 3x3) (36 transform points, the deep layers): its fp32 round-off is of the order of the direct K = 9C MFMA chain's
+    u4 = torch.empty(36, ko, c, device=cuda)
+    assert L.so_wino4_weights(wd.data_ptr(), u4.data_ptr(), ko, ko, c, 0, st) == 0
+    wws4 = torch.empty(L.so_wino4_ws_floats(n, h, w, c, ko), device=cuda)
+    y4 = torch.full((n, h, w, ko), float("nan"), device=cuda)
+    assert L.so_wino4_conv3x3(xd.data_ptr(), c, u4.data_ptr(), bd.data_ptr(), ko, gd.data_ptr() if gated else None, y4.data_ptr(), ko,
+                              n, h, w, c, ko, act, 0.0, wws4.data_ptr(), wws4.numel() * 4, ws.data_ptr(), ws.numel() * 4, st) == 0
+    e_4 = float((y4.cpu().double() - ref).abs().max())
+    print(f"   F(4x4,3x3): max err {e_4:.2e}")
+    assert e_4 <= 4 * e_d + 1.2e-5 * big, (e_4, e_d, big)
 
 
 def test_winograd_input_gradient_is_the_flipped_transposed_convolution(cuda, ops):
@@ -459,3 +469,10 @@ def test_winograd_input_gradient_is_the_flipped_transposed_convolution(cuda, ops
     dx2 = torch.full((n, h, w, c), float("nan"), device=cuda)
     assert L.so_wino_fused_conv3x3(dyd.data_ptr(), ko, uf.data_ptr(), None, 0, None, dx2.data_ptr(), c, n, h, w, ko, c, 0, 0.0, st) == 0
     assert_close(dx2, ref.float(), atol=3e-6 * float(ref.abs().max()), what="fused winograd input gradient")
+    u4 = torch.empty(36, c, ko, device=cuda)
+    assert L.so_wino4_weights(wd.data_ptr(), u4.data_ptr(), ko, ko, c, 1, st) == 0
+    wws4 = torch.empty(L.so_wino4_ws_floats(n, h, w, ko, c), device=cuda)
+    dx4 = torch.full((n, h, w, c), float("nan"), device=cuda)
+    assert L.so_wino4_conv3x3(dyd.data_ptr(), ko, u4.data_ptr(), None, 0, None, dx4.data_ptr(), c, n, h, w, ko, c, 0, 0.0,
+                              wws4.data_ptr(), wws4.numel() * 4, ws.data_ptr(), ws.numel() * 4, st) == 0
+    assert_close(dx4, ref.float(), atol=1.5e-5 * float(ref.abs().max()), what="F(4x4,3x3) input gradient")

@@ -68,6 +68,15 @@ def main():
                                                       T * ko, 16, None, None, None, 0, 0, 0, 0.0, ws.data_ptr(), ws.numel() * 4, st))
             td, tw, tf = timeit(direct), timeit(wino), timeit(fused)
             err_f = float((y2 - y0).abs().max())
+            U4 = torch.empty(36, ko, c, device=dev)
+            assert L.so_wino4_weights(wt.data_ptr(), U4.data_ptr(), ko, ko, c, 0, st) == 0
+            wws4 = torch.empty(L.so_wino4_ws_floats(nb, h, w, c, ko), device=dev)
+            y4 = torch.empty_like(y0)
+            f44 = lambda: L.so_wino4_conv3x3(x.data_ptr(), c, U4.data_ptr(), bias.data_ptr(), ko, None, y4.data_ptr(), ko, nb, h, w, c,  # noqa: E731
+                                             ko, 1, 0.0, wws4.data_ptr(), wws4.numel() * 4, ws.data_ptr(), ws.numel() * 4, st)
+            assert f44() == 0
+            t44 = timeit(f44)
+            err_44 = float((y4 - y0).abs().max())
             L.so_wino_fused_force_kb32(0)   # the 64-output-channel / two-blocks-per-CU instantiation for comparison
             tf32 = timeit(fused)
             L.so_wino_fused_force_kb32(1)
@@ -82,7 +91,7 @@ def main():
             gf = 2.0 * nb * h * w * ko * 9 * c / 1e9
             print(f"{nb},{h},{w},{c},{ko},{td:.1f},{gf / td * 1e3:.1f},{tw:.1f},{gf / tw * 1e3:.1f},{td / tw:.2f},-,{t_gemm:.1f},-,"
                   f"{err_d:.2e},{err_w:.2e},fused_us={tf:.1f},fused_eq_tflops={gf / tf * 1e3:.1f},fused_speedup={td / tf:.2f},"
-                  f"fused_vs_direct_maxdiff={err_f:.2e},fused_kb64_us={tf32:.1f}", flush=True)
+                  f"fused_vs_direct_maxdiff={err_f:.2e},fused_kb64_us={tf32:.1f},f44_us={t44:.1f},f44_vs_direct_maxdiff={err_44:.2e}", flush=True)
 
 
 if __name__ == "__main__":
