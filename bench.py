@@ -38,7 +38,8 @@ from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm")
+NKEYS = 40
+KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm", "winograd_gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
 KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = algorithmic (direct-convolution) FLOPs; executed = / 2.25
 WINOGRAD_KEY, WINOGRAD_FACTOR = 7, 2.25
@@ -236,15 +237,15 @@ def run_sams(args, trainer, L):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms = (ctypes.c_float * 32)()
-    fl = (ctypes.c_float * 32)()
-    cnt = (ctypes.c_int * 32)()
+    ms = (ctypes.c_float * NKEYS)()
+    fl = (ctypes.c_float * NKEYS)()
+    cnt = (ctypes.c_int * NKEYS)()
     L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
     if rank != 0:
         return
     kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / args.steps,
-                              "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(32) if cnt[k] > 0}
-    dom = max(range(32), key=lambda k: ms[k])
+                              "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(NKEYS) if cnt[k] > 0}
+    dom = max(range(NKEYS), key=lambda k: ms[k])
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     step_ms = 1e3 * elapsed / args.steps
     gf_step = GF_PER_FRAME["sams"] * args.batch * nfr
@@ -602,16 +603,16 @@ def main():
         log(f"gradient exchange exposed: {exposed_ms:.3f} ms/step ({1e3 * elapsed / args.steps:.3f} with, "
             f"{1e3 * float(t.item()) / args.steps:.3f} without collectives)")
 
-    ms = (ctypes.c_float * 32)()
-    fl = (ctypes.c_float * 32)()
-    cnt = (ctypes.c_int * 32)()
+    ms = (ctypes.c_float * NKEYS)()
+    fl = (ctypes.c_float * NKEYS)()
+    cnt = (ctypes.c_int * NKEYS)()
     L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
 
     if rank == 0:
         kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / prof_steps,
                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
-                   for k in range(32) if cnt[k] > 0}
-        dom = max(range(32), key=lambda k: ms[k])
+                   for k in range(NKEYS) if cnt[k] > 0}
+        dom = max(range(NKEYS), key=lambda k: ms[k])
         traffic = None  # HBM bytes per launch of the dominant instantiation, from the committed PMC passes
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -136,10 +136,11 @@ int so_igemm_plans_save(const char* path);
 int so_igemm_plans_load(const char* path);
 
 /* measurement hook (bench.py): when enabled, every MFMA launch is bracketed by HIP events on its own
- * stream.  so_prof_collect waits for them and fills HOST arrays of 32 entries, key = mode*8 + tile
- * (mode 0 fprop, 1 dgrad, 2 wgrad, 3 gemm; tile 0 64x64, 1 128x64, 2 64x128, 3 128x128, 4 128x128/8 waves,
- * 5 64x128/8 waves, 6 the 4x4x1-MFMA kernels for four-channel convolutions): summed milliseconds, summed algorithmic FLOPs
- * (2*M*N*K per launch), launch count.  Returns the number of launches collected and clears the list. */
+ * stream.  so_prof_collect waits for them and fills HOST arrays of 40 entries, key = group*8 + tile
+ * (group 0 fprop, 1 dgrad, 2 wgrad, 3 gemm, 4 Winograd-domain batched gemm (batch >= 16); tile 0 64x64, 1 128x64,
+ * 2 64x128, 3 128x128, 4 128x128/8 waves, 5 64x128/8 waves, 6 the 4x4x1-MFMA kernels for four-channel convolutions,
+ * 7 (group 0) the fused Winograd kernel): summed milliseconds, summed algorithmic FLOPs (2*M*N*K per launch; the fused
+ * Winograd kernel: the direct convolution's), launch count.  Returns the number of launches collected and clears the list. */
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
 

@@ -903,6 +903,9 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
   }
   if (timed) {
     rec.key = MODE * 8 + (NW == 8 ? (BM == 128 ? 4 : 5) : (BM == 128 ? 1 : 0) + (BN == 128 ? 2 : 0));
+    // batched GEMMs with >= 16 matrices are the Winograd-domain GEMMs of csrc/wino.hip (16 or 36 transform points): their own
+    // key group (4), so that they are not averaged with the ~10 us attention GEMMs that share the 64x64 instantiation
+    if (MODE == MODE_GEMM && p.nclass >= 16) rec.key += 8;
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
@@ -1120,11 +1123,12 @@ int so_igemm_plans_load(const char* path) {
 
 void so_prof_enable(int on) { g_prof_on = on != 0; }
 
-// Waits for every recorded launch, then fills per-key totals (key = mode*8 + tile index, 32 keys):
+// Waits for every recorded launch, then fills per-key totals (key = group*8 + tile index, 40 keys; groups: fprop, dgrad,
+// wgrad, gemm, Winograd-domain gemm):
 // out_ms[k] = summed kernel time in ms, out_flops[k] = summed algorithmic FLOPs, out_count[k] = launches.
 // Clears the record list.  Returns the number of launches collected.
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
-  for (int k = 0; k < 32; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
+  for (int k = 0; k < 40; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
   int n = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("SO_PROF_DUMP")) dump = fopen(path, "w");
