@@ -680,7 +680,7 @@ def test_sams_full_size_generator_pass_bs4_vs_oracle():
     """The reference-default generator at the batch bench.py times (bs = 4, 256x192, four previous frames): one forward +
     backward pass against oracle.generator_forward in fp32 - output and every parameter gradient element-wise.  These are the
     bs = 4 layer shapes (igemm instantiations / split-K plans from the committed plans file, Winograd forms) of the timed
-    step.  Rule: every gradient tensor within 2e-3 of its max of the fp32 oracle (absolute floor 1e-6 of the largest gradient
+    step.  Rule: every gradient tensor within 2e-3 of its max of the fp32 oracle (absolute floor 1e-5 of the largest gradient
     for the analytically-zero biases); at most 1 % of the tensors may instead sit within 5e-2 - a pre-activation on the other
     side of a ReLU kink (bracketed with the fp64 oracle at bs = 1 in the test above; three more fp64 passes at this size
     would cost four minutes of host time)."""
@@ -718,7 +718,9 @@ def test_sams_full_size_generator_pass_bs4_vs_oracle():
     assert e32 <= 1e-4 * max(1.0, out.detach().abs().max().item())
     got = {k: p.grad for k, p in gen.named_parameters() if p.grad is not None}
     assert set(got) == set(g32)
-    floor = 1e-6 * max(v.abs().max().item() for v in g32.values())
+    # floor: biases in front of a normalisation have analytically zero gradients - both sides hold round-off noise there
+    # (~6e-8 against a largest gradient of 4e-2)
+    floor = 1e-5 * max(v.abs().max().item() for v in g32.values())
     loose = []
     for k in sorted(got):
         err = (got[k].cpu() - g32[k]).abs().max().item()
