@@ -110,8 +110,6 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream);
 /* 1 (default) = 32 output channels per block, three blocks per CU; 0 = 64 per block for Ko >= 64 (two per CU) */
 void so_wino_fused_force_kb32(int on);
-/* 1 (default) = wave-private operand staging without a barrier in the K loop; 0 = the block-shared version */
-void so_wino_fused_wave_private(int on);
 
 /* torch.bmm replacement (sagan.py:44,50; warp.py:63):
  * C[b] = act(alpha[0] * opA(A[b]) opB(B[b]) + bias[n] + res[b]),  alpha/bias/res optional (NULL).

@@ -473,201 +473,6 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// Fused F(2x2, 3x3), WAVE-PRIVATE staging: no barrier in the K loop.
-// In the kernel above all four waves of a block meet at one barrier per K step (8 input channels = 16 MFMAs per wave); the
-// PMC passes show the waves 19 % of their time at barriers / waitcnt and the MFMA pipe 52 % busy.  But wave w (transformed
-// row w) needs only its OWN operands: of the weights the four transform points 4w..4w+3, of the raw patch two of the four
-// rows of every tile (a1, a2).  Here every wave stages exactly those by itself:
-//   * B fragments go straight from L2 into registers: in the U[c/8][xi][ko][8] layout the fragment of point xi for a lane
-//     (ko = lane % 32, k half = lane / 32) is one 16-byte load and the 64 lanes cover one contiguous 1 KB run - no LDS, no
-//     transposition, prefetched one step ahead;
-//   * the eight patch rows the wave needs (4 tile rows x {a1, a2}) x 18 columns x 8 channels are copied into a wave-private
-//     5 KB LDS region (two planes a1 / a2, the conflict-free slot layout of the shared version) - each patch row is loaded by
-//     two of the four waves (2x the small A traffic), and LDS operations of one wave execute in order, so a wave's writes of
-//     step s + 1 and its reads of step s need no barrier, only their own waitcnt.
-// The four waves of a block run independently until the epilogue (row combination of A^T M A through LDS).  40 KB LDS per
-// block, three blocks per CU.
-constexpr int WP_PLANE = 4 * WF_AROW * WF_APIX;      // 640 floats: 4 tile rows x 20 slots x 8 channels
-constexpr int WP_STAGE = 2 * WP_PLANE;               // a1 plane + a2 plane = 5 KB
-constexpr int WP_WAVE = 2 * WP_STAGE;                // double buffered
-constexpr int WP_LDS_FLOATS = 4 * WP_WAVE;           // 40 KB; the epilogue re-uses the first 32 KB
-
-__global__ __launch_bounds__(WF_NT, 3) void wino_fused_wp_k(const WinoP p) {
-  constexpr int KB = 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
-  float* Aw = smem + wi * WP_WAVE;
-
-  const unsigned tot = gridDim.x, lin = blockIdx.x;
-  const unsigned xper = tot >> 3, xrem = tot & 7, xcd = lin & 7;
-  const unsigned lg = xcd * xper + (xcd < xrem ? xcd : xrem) + (lin >> 3);
-  const int kb = (int)(lg % (unsigned)p.nkb);
-  const int patch = (int)(lg / (unsigned)p.nkb);
-  const int pxb = patch % p.pbx;
-  const int t2 = patch / p.pbx;
-  const int pyb = t2 % p.pby;
-  const int n = t2 / p.pby;
-  const int k0 = kb * KB;
-  const int h_org = 8 * pyb - 1, w_org = 16 * pxb - 1;
-
-  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, (int)p.u_bytes, 0x00020000);
-
-  const int a1 = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
-  const int a2 = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-  const float sgn = wi == 1 ? 1.f : -1.f;
-
-  // ---- A loader: 2 planes x 4 tile rows x 18 pixels x 2 quads = 288 items over 64 lanes (5 passes) ---------------------
-  int a_src[5], a_dst[5];
-#pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    const int id = lane + 64 * m;
-    a_src[m] = -1;
-    a_dst[m] = -1;
-    if (id < 288) {
-      const int plane = id / 144, rem = id - plane * 144;
-      const int row = rem / 36, r2 = rem - row * 36;
-      const int px = r2 >> 1, q = r2 & 1;
-      const int h = h_org + 2 * row + (plane ? a2 : a1), w = w_org + px;
-      if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) a_src[m] = ((n * p.H + h) * p.W + w) * p.ldx + q * 4;
-      const int cs = (px >> 1) + (px & 1) * 9;
-      a_dst[m] = plane * WP_PLANE + (row * WF_AROW + cs) * WF_APIX + ((q ^ (row & 1)) << 2);
-    }
-  }
-  auto load_a = [&](int s, f32x4 (&dst)[5]) {
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      const int c = 8 * s + ((lane + 64 * m) & 1) * 4;     // (id & 1) == quad for every item: 144 and 36 are even
-      const bool ok = (a_src[m] >= 0) & (c < p.C);
-      dst[m] = wf_bload(rX, ok ? (unsigned)(a_src[m] + 8 * s) * 4u : WF_OOB);
-    }
-  };
-  auto store_a = [&](int st, const f32x4 (&v)[5]) {
-#pragma unroll
-    for (int m = 0; m < 5; ++m)
-      if (a_dst[m] >= 0) *reinterpret_cast<f32x4*>(Aw + st * WP_STAGE + a_dst[m]) = v[m];
-  };
-  // ---- B fragments straight from global: point xi = 4 wi + j, row ko = k0 + li, channels 8 s + 4 lh .. + 3 --------------
-  const bool b_ok = k0 + li < p.Ko;
-  const int b_src0 = ((4 * wi) * p.Ko + k0 + li) * 8 + lh * 4;
-  const int b_xi = p.Ko * 8;            // next transform point
-  const int b_step = 16 * p.Ko * 8;     // next K step
-  auto load_b = [&](int s, f32x4 (&dst)[4]) {
-    const bool ok = b_ok & (s < p.nks);
-    const int base = b_src0 + s * b_step;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dst[j] = wf_bload(rU, ok ? (unsigned)(base + j * b_xi) * 4u : WF_OOB);
-  };
-
-  // fragment addresses inside a stage: tile (ttx, tty) of this lane, plane a1 / a2, patch column b
-  const int ttx = li & 7, tty = li >> 3;
-  const int fa_0 = (tty * WF_AROW + ttx) * WF_APIX + ((lh ^ (tty & 1)) << 2);
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  f32x4 ra[5], bf0[4], bf1[4];
-  {
-    f32x4 a0[5];
-    load_a(0, a0);
-    load_b(0, bf0);
-    load_a(1, ra);
-    load_b(1, bf1);
-    store_a(0, a0);
-  }
-  // one K step: fragments of step s from LDS stage `rd` and the B registers `bf`; stages the patch of step s + 1 into the
-  // other LDS stage, issues the loads of step s + 2 (A into `ra`, B into the registers just consumed)
-  auto kstep = [&](int rd, f32x4 (&bf)[4], int s_next) {
-    const float* as = Aw + rd * WP_STAGE;
-    f32x4 t[4], v[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const f32x4 d1 = *reinterpret_cast<const f32x4*>(as + fa_0 + ((b >> 1) + (b & 1) * 9) * WF_APIX);
-      const f32x4 d2 = *reinterpret_cast<const f32x4*>(as + WP_PLANE + fa_0 + ((b >> 1) + (b & 1) * 9) * WF_APIX);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[b][e] = __builtin_fmaf(sgn, d2[e], d1[e]);
-    }
-    v[0] = t[0] - t[2];
-    v[1] = t[1] + t[2];
-    v[2] = t[2] - t[1];
-    v[3] = t[1] - t[3];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
-    WF_SB();
-    store_a(rd ^ 1, ra);       // wave-private: ordered behind this wave's own reads of that stage by program order
-    WF_SB();
-#pragma unroll
-    for (int e = 2; e < 4; ++e)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[j][e], acc[j], 0, 0, 0);
-    WF_SB();
-    load_a(s_next, ra);
-    load_b(s_next, bf);
-  };
-  for (int s = 0; s < p.nks; s += 2) {   // an odd trailing step multiplies zeros (past-the-end loads return 0)
-    kstep(0, bf0, s + 2);
-    kstep(1, bf1, s + 3);
-  }
-
-  // ---- epilogue: A^T M A (as in wino_fused_k<1>) ------------------------------------------------------------------------
-  __syncthreads();              // every wave is done with its staging region before it becomes the exchange buffer
-  float* Ps = smem;             // [i 4][b 2][tile 32][ko 32]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    const float p0 = acc[0][r] + acc[1][r] + acc[2][r];
-    const float p1 = acc[1][r] - acc[2][r] - acc[3][r];
-    Ps[((wi * 2 + 0) * 32 + tile) * KB + li] = p0;
-    Ps[((wi * 2 + 1) * 32 + tile) * KB + li] = p1;
-  }
-  __syncthreads();
-  {
-    const int tile = tid >> 3, kq = (tid & 7) * 4;
-    const int ty = 4 * pyb + (tile >> 3), tx = 8 * pxb + (tile & 7);
-    const int ko = k0 + kq;
-    if (ko < p.Ko) {
-      f32x4 P[4][2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) P[i][b] = *reinterpret_cast<const f32x4*>(Ps + ((i * 2 + b) * 32 + tile) * KB + kq);
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = (ko + q < p.nbias) ? p.bias[ko + q] : 0.f;
-      }
-      const float slope = p.act == SO_ACT_RELU ? 0.f : (p.act == SO_ACT_LEAKY ? p.act_param : 1.f);
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int h = 2 * ty + a;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int w = 2 * tx + b;
-          if (h < p.H && w < p.W) {
-            f32x4 v = (a == 0 ? P[0][b] + P[1][b] + P[2][b] : P[1][b] - P[2][b] - P[3][b]) + bv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * slope;
-            const long long off = ((long long)(n * p.H + h) * p.W + w) * p.ldy + ko;
-            if (p.gate) {
-              const f32x4 g = ld4(p.gate + off);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = g[q] > 0.f ? v[q] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(p.y + off) = v;
-          }
-        }
-      }
-    }
-  }
-}
-
 // weights in the fused kernel's order: U[c/8][xi][ko][8] (channels beyond C zero-filled up to a multiple of 8)
 __global__ __launch_bounds__(256) void wino_weights_fused_k(const float* __restrict__ w, float* __restrict__ U, int Ko, int C,
                                                             int Kw, int flip_transpose) {
@@ -983,9 +788,10 @@ int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int f
 // step: 557-558 vs 551 frames/s) or 64 for Ko >= 64 (two blocks per CU, the A fragments feed 32 MFMAs instead of 16).
 static int g_wino_force_nkg1 = 1;
 void so_wino_fused_force_kb32(int on) { g_wino_force_nkg1 = on; }
-// 1 (default) = wave-private staging, no barrier in the K loop (wino_fused_wp_k); 0 = block-shared staging (wino_fused_k)
-static int g_wino_wave_private = 1;
-void so_wino_fused_wave_private(int on) { g_wino_wave_private = on; }
+// (A barrier-free variant - every wave staging only its own operands: B fragments straight from L2 into registers, its 8 of
+//  the 10 patch rows in a wave-private LDS region - was built and measured in round 3 (commit 3c3fa6b): correct, but 12 % SLOWER
+//  (conv1_2 176 vs 162 us, conv2_2 150 vs 131 us, step 576 vs 589 frames/s: 2x the patch loads, 5 instead of 1.4 loads per
+//  lane and step, spills at 168 VGPRs), i.e. the per-step barrier is not what holds the kernel at 53 % of the pipe.  Removed.)
 
 int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream) {
@@ -1024,9 +830,6 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
                                  (hipStream_t)stream);
   if (nkg == 2)
     hipLaunchKernelGGL(wino_fused_k<2>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
-  else if (g_wino_wave_private)
-    hipLaunchKernelGGL(wino_fused_wp_k, dim3((unsigned)blocks), dim3(WF_NT), (size_t)WP_LDS_FLOATS * sizeof(float),
-                       (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(wino_fused_k<1>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);

@@ -80,11 +80,7 @@ def main():
             L.so_wino_fused_force_kb32(0)   # the 64-output-channel / two-blocks-per-CU instantiation for comparison
             tf32 = timeit(fused)
             L.so_wino_fused_force_kb32(1)
-            L.so_wino_fused_wave_private(0)  # block-shared staging (one barrier per K step) for comparison
-            assert fused() == 0
-            tshared = timeit(fused)
-            err_shared = float((y2 - y0).abs().max())
-            L.so_wino_fused_wave_private(1)
+
             err_d = err_w = float("nan")
             if nb * h * w <= 8 * 64 * 48:
                 ref = torch.nn.functional.conv2d(x.view(nb, h, w, c).permute(0, 3, 1, 2).double().cpu(), wt.permute(0, 3, 1, 2).double().cpu(),
@@ -96,7 +92,7 @@ def main():
             gf = 2.0 * nb * h * w * ko * 9 * c / 1e9
             print(f"{nb},{h},{w},{c},{ko},{td:.1f},{gf / td * 1e3:.1f},{tw:.1f},{gf / tw * 1e3:.1f},{td / tw:.2f},-,{t_gemm:.1f},-,"
                   f"{err_d:.2e},{err_w:.2e},fused_us={tf:.1f},fused_eq_tflops={gf / tf * 1e3:.1f},fused_speedup={td / tf:.2f},"
-                  f"fused_vs_direct_maxdiff={err_f:.2e},fused_kb64_us={tf32:.1f},fused_shared_us={tshared:.1f},shared_maxdiff={err_shared:.2e},f44_us={t44:.1f},f44_vs_direct_maxdiff={err_44:.2e}", flush=True)
+                  f"fused_vs_direct_maxdiff={err_f:.2e},fused_kb64_us={tf32:.1f},f44_us={t44:.1f},f44_vs_direct_maxdiff={err_44:.2e}", flush=True)
 
 
 if __name__ == "__main__":
