@@ -225,6 +225,66 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_k(const float* __restrict_
   }
 }
 
+// Tiled form for the large levels: a block takes UP_TH x UP_TW source pixels x UP_CC channels, stages them (+ a one-pixel
+// clamped halo) through LDS with the activation applied ONCE per source element, and writes the 2*UP_TH x 2*UP_TW outputs.
+// The element-per-thread form above fetches four neighbours per output (4x the output size through the vector L1) and
+// evaluates the activation four times per source element (GELU: erf) - 3.1 of 8 TB/s on the 128x96 -> 256x192 level.
+// Same taps, weights and expression per output as upsample2x_fwd_k: the results are bit-identical.
+constexpr int UP_TH = 8, UP_TW = 8, UP_CC = 32, UP_CQ = UP_CC / 4;
+__global__ __launch_bounds__(256) void upsample2x_fwd_tiled_k(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                              int ldy, unsigned H, unsigned W, unsigned tiles_w,
+                                                              unsigned tiles_hw, unsigned cchunks, int act, float act_param,
+                                                              const float* __restrict__ x2, int ldx2, unsigned C1) {
+  __shared__ f32x4 tile[(UP_TH + 2) * (UP_TW + 2) * UP_CQ];
+  unsigned b = blockIdx.x;
+  const unsigned cc = b % cchunks; b /= cchunks;
+  const unsigned tw = b % tiles_w;
+  const unsigned th = (b % tiles_hw) / tiles_w;
+  const unsigned n = b / tiles_hw;
+  const int h_lo = (int)(th * UP_TH) - 1, w_lo = (int)(tw * UP_TW) - 1;
+  const unsigned c0 = cc * UP_CC;
+  const bool first = c0 < C1;
+  const int ld = first ? ldx : ldx2;
+  const float* base = (first ? x + c0 : x2 + (c0 - C1)) + (size_t)n * H * W * ld;
+  for (unsigned i = threadIdx.x; i < (UP_TH + 2) * (UP_TW + 2) * UP_CQ; i += 256u) {
+    const unsigned q = i % UP_CQ, pix = i / UP_CQ;
+    int h = h_lo + (int)(pix / (UP_TW + 2)), w = w_lo + (int)(pix % (UP_TW + 2));
+    h = h < 0 ? 0 : (h > (int)H - 1 ? (int)H - 1 : h);
+    w = w < 0 ? 0 : (w > (int)W - 1 ? (int)W - 1 : w);
+    f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)h * W + w) * ld + q * 4);
+    if (act != SO_ACT_NONE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = so_actf(act, v[k], act_param);
+    }
+    tile[i] = v;
+  }
+  __syncthreads();
+  const unsigned q = threadIdx.x % UP_CQ;
+  const unsigned ocol = (threadIdx.x / UP_CQ) % (2 * UP_TW);
+  const unsigned wo = tw * (2 * UP_TW) + ocol;
+  if (wo >= 2 * W) return;
+  int w0, w1;
+  float lw0, lw1;
+  up_src((int)wo, (int)W, w0, w1, lw0, lw1);
+  w0 -= w_lo; w1 -= w_lo;
+  constexpr unsigned ROWS_PER_PASS = 256 / (UP_CQ * 2 * UP_TW);
+#pragma unroll 2
+  for (unsigned orow = threadIdx.x / (UP_CQ * 2 * UP_TW); orow < 2 * UP_TH; orow += ROWS_PER_PASS) {
+    const unsigned ho = th * (2 * UP_TH) + orow;
+    if (ho >= 2 * H) break;
+    int h0, h1;
+    float lh0, lh1;
+    up_src((int)ho, (int)H, h0, h1, lh0, lh1);
+    h0 -= h_lo; h1 -= h_lo;
+    const f32x4 a00 = tile[(h0 * (UP_TW + 2) + w0) * UP_CQ + q], a01 = tile[(h0 * (UP_TW + 2) + w1) * UP_CQ + q];
+    const f32x4 a10 = tile[(h1 * (UP_TW + 2) + w0) * UP_CQ + q], a11 = tile[(h1 * (UP_TW + 2) + w1) * UP_CQ + q];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = lh0 * (lw0 * a00[k] + lw1 * a01[k]) + lh1 * (lw0 * a10[k] + lw1 * a11[k]);
+    *reinterpret_cast<f32x4*>(y + ((size_t)(n * 2 * H + ho) * (2 * W) + wo) * ldy + c0 + q * 4) = o;
+  }
+}
+
 // Gather form of the backward pass (deterministic, no atomics): each input pixel i receives weight from
 // output pixels 2i-1 (.25), 2i (.75 or 1 at i==0), 2i+1 (.75 or 1 at i==in-1), 2i+2 (.25).
 __device__ __forceinline__ void up_taps(int i, int in, int o[4], float w[4]) {
@@ -278,6 +338,68 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_k(const float* __restrict_
       for (int i = 0; i < VEC; ++i) acc.v[i] *= so_actg(act, xv.v[i], act_param);
     }
     stp<VEC>(first ? dx + pix * lddx + c0 : dx2 + pix * lddx2 + (c0 - C1), acc);
+  }
+}
+
+// Tiled backward pass for the large levels: the (2*UP_TH + 2) x (2*UP_TW + 2) patch of dy a block's UP_TH x UP_TW source
+// pixels gather from goes through LDS once (the element-per-thread form fetches every dy element four times); taps outside
+// the image carry weight 0 and are skipped exactly as above, so the sums have the same terms in the same order.
+template <int TH>
+__global__ __launch_bounds__(256) void upsample2x_bwd_tiled_k(const float* __restrict__ dy, int lddy, float* __restrict__ dx,
+                                                              int lddx, unsigned H, unsigned W, unsigned tiles_w,
+                                                              unsigned tiles_hw, unsigned cchunks,
+                                                              const float* __restrict__ x, int ldx, int act, float act_param,
+                                                              float* __restrict__ dx2, int lddx2,
+                                                              const float* __restrict__ x2, int ldx2, unsigned C1) {
+  constexpr int PH = 2 * TH + 2, PW = 2 * UP_TW + 2;
+  __shared__ f32x4 patch[PH * PW * UP_CQ];
+  unsigned b = blockIdx.x;
+  const unsigned cc = b % cchunks; b /= cchunks;
+  const unsigned tw = b % tiles_w;
+  const unsigned th = (b % tiles_hw) / tiles_w;
+  const unsigned n = b / tiles_hw;
+  const int oh_lo = 2 * (int)(th * TH) - 1, ow_lo = 2 * (int)(tw * UP_TW) - 1;
+  const unsigned c0 = cc * UP_CC, Ho = 2 * H, Wo = 2 * W;
+  const float* base = dy + (size_t)n * Ho * Wo * lddy + c0;
+  for (unsigned i = threadIdx.x; i < PH * PW * UP_CQ; i += 256u) {
+    const unsigned q = i % UP_CQ, pix = i / UP_CQ;
+    const int oh = oh_lo + (int)(pix / PW), ow = ow_lo + (int)(pix % PW);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (oh >= 0 && oh < (int)Ho && ow >= 0 && ow < (int)Wo)
+      v = *reinterpret_cast<const f32x4*>(base + ((size_t)oh * Wo + ow) * lddy + q * 4);
+    patch[i] = v;
+  }
+  __syncthreads();
+  const unsigned q = threadIdx.x % UP_CQ;
+  const bool first = c0 < C1;
+  for (unsigned p = threadIdx.x / UP_CQ; p < TH * UP_TW; p += 256 / UP_CQ) {
+    const unsigned hi = th * TH + p / UP_TW, wi = tw * UP_TW + p % UP_TW;
+    if (hi >= H || wi >= W) continue;
+    int oh[4], ow[4];
+    float wh[4], ww[4];
+    up_taps((int)hi, (int)H, oh, wh);
+    up_taps((int)wi, (int)W, ow, ww);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (wh[a] == 0.f) continue;
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) {
+        if (ww[b2] == 0.f) continue;
+        const f32x4 g = patch[((oh[a] - oh_lo) * PW + (ow[b2] - ow_lo)) * UP_CQ + q];
+        const float wgt = wh[a] * ww[b2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += wgt * g[k];
+      }
+    }
+    const size_t pix = (size_t)(n * H + hi) * W + wi;
+    const unsigned c = c0 + q * 4;
+    if (act != SO_ACT_NONE) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(first ? x + pix * ldx + c : x2 + pix * ldx2 + (c - C1));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] *= so_actg(act, xv[k], act_param);
+    }
+    *reinterpret_cast<f32x4*>(first ? dx + pix * lddx + c : dx2 + pix * lddx2 + (c - C1)) = acc;
   }
 }
 
@@ -691,6 +813,12 @@ int so_ohwi_to_ihwo(const float* w, float* wt, int Ko, int taps, int C, void* st
   return SO_LAUNCH_CHECK();
 }
 
+// SO_UPSAMPLE_TILED=0: the element-per-thread kernels for every level (A/B measurements)
+static bool so_upsample_tiled_enabled() {
+  static const bool on = [] { const char* e = getenv("SO_UPSAMPLE_TILED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 int so_upsample2x_cat_fwd(const float* x1, int ldx1, int C1, const float* x2, int ldx2, int C2, float* y, int ldy,
                           int Nb, int H, int W, int act, float act_param, void* stream) {
   const int C = C1 + (x2 ? C2 : 0);
@@ -698,6 +826,15 @@ int so_upsample2x_cat_fwd(const float* x1, int ldx1, int C1, const float* x2, in
   if (total <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const bool v2 = !x2 || ((C1 & 3) == 0 && (C2 & 3) == 0 && (ldx2 & 3) == 0 && al16(x2));
+  // large levels: source tile staged through LDS (activation once per source element, one global fetch per element)
+  if (VEC_OK2(x1, ldx1, y, ldy, C) && v2 && C % UP_CC == 0 && (!x2 || C1 % UP_CC == 0) && (long long)H * W >= 192 &&
+      so_upsample_tiled_enabled()) {
+    const unsigned tiles_w = (W + UP_TW - 1) / UP_TW, tiles_h = (H + UP_TH - 1) / UP_TH, cchunks = C / UP_CC;
+    hipLaunchKernelGGL(upsample2x_fwd_tiled_k, dim3((unsigned)Nb * tiles_h * tiles_w * cchunks), dim3(256), 0, st, x1, ldx1, y,
+                       ldy, (unsigned)H, (unsigned)W, tiles_w, tiles_h * tiles_w, cchunks, act, act_param, x2, ldx2,
+                       (unsigned)(x2 ? C1 : C));
+    return SO_LAUNCH_CHECK();
+  }
   if (VEC_OK2(x1, ldx1, y, ldy, C) && v2)
     hipLaunchKernelGGL(upsample2x_fwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x1, ldx1, y,
                        ldy, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, act, act_param, x2, ldx2, (unsigned)C1);
@@ -726,6 +863,23 @@ int so_upsample2x_cat_bwd(const float* x1, int ldx1, int C1, const float* x2, in
   hipStream_t st = (hipStream_t)stream;
   const bool xok = act == SO_ACT_NONE || ((ldx1 & 3) == 0 && al16(x1) && (!dx2 || ((ldx2 & 3) == 0 && al16(x2))));
   const bool v2 = !dx2 || ((C1 & 3) == 0 && (C2 & 3) == 0 && (lddx2 & 3) == 0 && al16(dx2));
+  if (VEC_OK2(dy, lddy, dx1, lddx1, C) && xok && v2 && C % UP_CC == 0 && (!dx2 || C1 % UP_CC == 0) && (long long)H * W >= 192 &&
+      so_upsample_tiled_enabled()) {
+    static const int bth = [] { const char* e = getenv("SO_UPSAMPLE_BWD_TH"); return e ? atoi(e) : 4; }();
+    const unsigned tiles_w = (W + UP_TW - 1) / UP_TW, cchunks = C / UP_CC;
+    if (bth == 8) {
+      const unsigned tiles_h = (H + 7) / 8;
+      hipLaunchKernelGGL(upsample2x_bwd_tiled_k<8>, dim3((unsigned)Nb * tiles_h * tiles_w * cchunks), dim3(256), 0, st, dy, lddy,
+                         dx1, lddx1, (unsigned)H, (unsigned)W, tiles_w, tiles_h * tiles_w, cchunks, x1, ldx1, act, act_param, dx2,
+                         lddx2, x2, ldx2, (unsigned)(dx2 ? C1 : C));
+    } else {
+      const unsigned tiles_h = (H + 3) / 4;
+      hipLaunchKernelGGL(upsample2x_bwd_tiled_k<4>, dim3((unsigned)Nb * tiles_h * tiles_w * cchunks), dim3(256), 0, st, dy, lddy,
+                         dx1, lddx1, (unsigned)H, (unsigned)W, tiles_w, tiles_h * tiles_w, cchunks, x1, ldx1, act, act_param, dx2,
+                         lddx2, x2, ldx2, (unsigned)(dx2 ? C1 : C));
+    }
+    return SO_LAUNCH_CHECK();
+  }
   if (VEC_OK2(dy, lddy, dx1, lddx1, C) && xok && v2)
     hipLaunchKernelGGL(upsample2x_bwd_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, dy, lddy, dx1,
                        lddx1, (unsigned)Nb, (unsigned)H, (unsigned)W, (unsigned)C, x1, ldx1, act, act_param, dx2, lddx2, x2,

@@ -82,15 +82,30 @@ __global__ __launch_bounds__(256) void thin_conv_k(const ThinConv p) {
   for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wrow = wl + (lane & 3) * KP;
   const int Q = p.IC >> 2;
-  for (int q = 0; q < Q; ++q) {
-    const f32x4 xv = thin_bload(rs, base + (unsigned)q * 16u);
-    f32x4 wv[T];
+  // The lane's pixel is fetched PF quads (64 bytes) ahead: one 16-byte load per 36 MFMAs left a single request in flight
+  // per wave and the loop ran at the HBM latency (58 us for the 128 -> 4 layer against 16 us of MFMA issue).  Quads past
+  // the last channel read through an out-of-range offset (zeros) and are never multiplied.
+  constexpr int PF = 4;
+  f32x4 cur[PF], nxt[PF];
 #pragma unroll
-    for (int t = 0; t < T; ++t) wv[t] = *reinterpret_cast<const f32x4*>(wrow + t * p.IC + q * 4);
+  for (int j = 0; j < PF; ++j) cur[j] = thin_bload(rs, j < Q ? base + (unsigned)j * 16u : SO_OOB);
+  for (int q0 = 0; q0 < Q; q0 += PF) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < PF; ++j) nxt[j] = thin_bload(rs, q0 + PF + j < Q ? base + (unsigned)(q0 + PF + j) * 16u : SO_OOB);
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[t][k], xv[k], acc[t], 0, 0, 0);
+    for (int j = 0; j < PF; ++j) {
+      if (q0 + j < Q) {
+        f32x4 wv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) wv[t] = *reinterpret_cast<const f32x4*>(wrow + t * p.IC + (q0 + j) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[t][k], cur[j][k], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
   }
 
   f32x4 v = acc[0];
@@ -165,15 +180,16 @@ __global__ __launch_bounds__(256) void thin_wgrad_k(const ThinWgrad p) {
     __syncthreads();
     const float* xrow = p.x + (long long)(n * p.H + hi) * p.W * p.ldx + c0 + lane;
     const float* dl = dyl + (lane & 3);
-    for (int wi0 = sub; wi0 < p.W; wi0 += 4 * subs) {
-      float xv[4];
+    constexpr int U = 8;  // x values in flight per lane (4 left the loop waiting on HBM: 24 KB outstanding per CU)
+    for (int wi0 = sub; wi0 < p.W; wi0 += U * subs) {
+      float xv[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int wi = wi0 + u * subs;
         xv[u] = wi < p.W ? xrow[(long long)wi * p.ldx] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int wi = wi0 + u * subs;
         const int wic = wi < p.W ? wi : 0;  // xv is 0 beyond the row; keep the LDS address in range
 #pragma unroll

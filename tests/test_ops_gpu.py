@@ -65,6 +65,7 @@ CONV_CASES = [
     (2, 128, 9, 7, 3, 3, 1, 1),        # three output channels padded to four, ragged pixel count
     (2, 4, 16, 12, 64, 3, 1, 1),       # four input channels: 4x4x1-MFMA input gradient (VGG conv1_1 class)
     (3, 64, 8, 6, 4, 1, 1, 0),         # 1x1 with four output channels
+    (2, 40, 9, 7, 4, 3, 1, 1),         # four output channels, 10 channel quads: ragged tail of the 4-quad prefetch groups
 ]
 
 
@@ -220,6 +221,22 @@ def test_upsample_of_unmaterialised_concat(ops, cuda, c1, c2, kind, ref):
     compare_fwd_bwd(lambda a_, b_: ops.upsample2x_bilinear_cat(a_, b_, kind),
                     lambda a_, b_: F.interpolate(ref(torch.cat([a_, b_], 1)), scale_factor=2, mode="bilinear", align_corners=False),
                     [(a, True), (b, True)], cuda, atol=2e-6, what=f"cat+{kind}+upsample")
+
+
+@pytest.mark.parametrize("kind,ref", [("gelu", F.gelu), (None, lambda t: t)])
+@pytest.mark.parametrize("hw", [(28, 21), (32, 24), (19, 40)])   # edge tiles in both directions / exact tiles
+def test_upsample_tiled_levels(ops, cuda, kind, ref, hw):
+    """The LDS-tiled kernels of the large levels (>= 512 source pixels, channels in chunks of 32): single source and the
+    unmaterialised concatenation, forward and backward, against torch."""
+    h, w = hw
+    x = rnd(2, 64, h, w, seed=23)
+    compare_fwd_bwd(lambda t: ops.upsample2x_bilinear(t, kind),
+                    lambda t: F.interpolate(ref(t), scale_factor=2, mode="bilinear", align_corners=False),
+                    [(x, True)], cuda, atol=2e-6, what=f"tiled {kind}+upsample {hw}")
+    a, b = rnd(2, 32, h, w, seed=24), rnd(2, 64, h, w, seed=25)
+    compare_fwd_bwd(lambda a_, b_: ops.upsample2x_bilinear_cat(a_, b_, kind),
+                    lambda a_, b_: F.interpolate(ref(torch.cat([a_, b_], 1)), scale_factor=2, mode="bilinear", align_corners=False),
+                    [(a, True), (b, True)], cuda, atol=2e-6, what=f"tiled cat+{kind}+upsample {hw}")
 
 
 def test_upsample_maxpool_cat(ops, cuda):
