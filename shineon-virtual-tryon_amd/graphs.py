@@ -84,10 +84,15 @@ class GraphedChainedStep:
     Forward and backward of the warp model are captured separately on one capture stream (autograd runs every backward
     node on the stream of its forward op), the way torch.cuda.make_graphed_callables does."""
 
-    def __init__(self, warp, optw, unet, optu, sample_batch, warmup=2):
+    def __init__(self, warp, optw, unet, optu, sample_batch, warmup=2, exchange_w=None, exchange_u=None):
+        """exchange_w / exchange_u: trainer.BucketedExchange of the warp / try-on optimizer - their counter bump and "bucket
+        ready" signal kernels become nodes of the warp-backward / try-on graph, so each model's gradient buckets can be
+        exchanged and applied while the rest of its backward pass is still running."""
         from . import ops
 
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
+        self.exchange_w, self.exchange_u = exchange_w, exchange_u
+        exw, exu = exchange_w, exchange_u
         clone = lambda: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}
         self.batch_warp, self.batch_tryon = clone(), clone()
         sb = self.batch_warp
@@ -102,12 +107,20 @@ class GraphedChainedStep:
             with ops.workspace_lane(8):
                 optw.zero_grad()
                 rw = warp.training_step(sb, 0)
+                if exw is not None:
+                    exw.begin()
                 rw.minimize.backward()
+                if exw is not None:
+                    exw.end()
             b2 = dict(self.batch_tryon)
             b2["cloth"] = warp.warped_cloth
             optu.zero_grad()
+            if exu is not None:
+                exu.begin()
             ru = unet.training_step(b2, 0)
             ru.minimize.backward()
+            if exu is not None:
+                exu.end()
 
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -124,7 +137,11 @@ class GraphedChainedStep:
                 optw.zero_grad()
                 rw = warp.training_step(sb, 0)
             with torch.cuda.graph(self.g_wb, stream=cs):
+                if exw is not None:
+                    exw.begin()
                 rw.minimize.backward()
+                if exw is not None:
+                    exw.end()
         self.result_warp = _detached(rw)
         del rw
         self.warped = warp.warped_cloth              # static output of the warp-forward graph
@@ -134,8 +151,12 @@ class GraphedChainedStep:
         b2["cloth"] = self.cloth_tryon
         with torch.cuda.graph(self.g_u):
             optu.zero_grad()
+            if exu is not None:
+                exu.begin()
             ru = unet.training_step(b2, 0)
             ru.minimize.backward()
+            if exu is not None:
+                exu.end()
         self.result_tryon = _detached(ru)
         del ru
         self._first = True
@@ -173,11 +194,15 @@ class GraphedChainedStep:
         self.cloth_tryon.copy_(self.warped, non_blocking=True)
         self.cloth_taken.record(main)
         self.g_u.replay()
+        if self.exchange_u is not None:
+            self.exchange_u.note_replay()
 
     def launch_warp_backward(self):
         """side stream: warp backward; the caller then issues the warp all-reduce / Adam under `with self.on_side():`."""
         with torch.cuda.stream(self.side):
             self.g_wb.replay()
+        if self.exchange_w is not None:
+            self.exchange_w.note_replay()
 
     def on_side(self):
         return torch.cuda.stream(self.side)

@@ -30,6 +30,17 @@ logger = logging.getLogger("logger")
 def init_distributed(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* if launched under torchrun."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and not dist.is_initialized() and _single_rank_group() and torch.cuda.is_available():
+        # SHINEON_SINGLE_RANK_GROUP=1: a ONE-rank RCCL group, so that a one-GPU box runs the whole exchange path for real -
+        # communicator set-up, per-bucket all-reduce on the communication stream behind the in-graph signals, broadcasts
+        import socket
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        torch.cuda.set_device(int(os.environ.get("SHINEON_LOCAL_DEVICE", "0")))
+        dist.init_process_group(backend=backend or "nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        return 0, 1
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0, max(world, 1)
     # SHINEON_DIST_BACKEND=gloo: functional runs of the multi-rank code path where RCCL cannot be used (e.g. two ranks
@@ -50,6 +61,16 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _single_rank_group():
+    return os.environ.get("SHINEON_SINGLE_RANK_GROUP", "0") == "1"
+
+
+def _collective():
+    """True when gradients and buffers have to travel: more than one rank - or the one-rank RCCL group of
+    SHINEON_SINGLE_RANK_GROUP=1 (init_distributed), where every collective is issued although nothing changes hands."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_group())
+
+
 class GradientAllReducer:
     """Mean all-reduce of a flat gradient slab in `n_buckets` contiguous pieces.
 
@@ -59,17 +80,19 @@ class GradientAllReducer:
     def __init__(self, flat_grads, n_buckets=4, group=None):
         self.flat = flat_grads
         self.group = group
+        n_buckets = max(1, int(os.environ.get("SHINEON_REDUCER_BUCKETS", n_buckets)))
         n = flat_grads.numel()
         step = (n + n_buckets - 1) // n_buckets
         step = (step + 1023) // 1024 * 1024
         self.buckets = [flat_grads[i:min(i + step, n)] for i in range(0, n, step)]
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = _collective()   # False: no collective is issued (one process; bench.py also clears it to time a step without)
         self._works = None
 
     def start(self):
         """Issue the asynchronous all-reduce of every bucket (RCCL runs on its own stream, ordered after the work
         already queued on the current stream), so that it overlaps whatever is launched next."""
-        if self.world > 1:
+        if self.active:
             self._works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
 
     def finish(self):
@@ -83,8 +106,8 @@ class GradientAllReducer:
 
     def all_reduce(self):
         """start() + finish(): returns the factor the optimizer must scale gradients by (1 / world)."""
-        if self.world == 1:
-            return 1.0
+        if not self.active:
+            return 1.0 / self.world
         self.start()
         return self.finish()
 
@@ -116,6 +139,7 @@ class BucketedExchange:
         if not self.L.so_signal_can_wait():
             raise RuntimeError("this device does not support hipStreamWaitValue32; use GradientAllReducer")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = _collective()
         table = optimizer.slot_table()
         total = optimizer.flat_grads.numel()
         want = max(1, int(bucket_bytes) // 4)
@@ -222,7 +246,7 @@ class BucketedExchange:
             lo, hi, _ = self.buckets[b]
             self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, self.wait_mode, self.comm.cuda_stream), "stream_wait_ge")
             with torch.cuda.stream(self.comm):
-                if self.world > 1:
+                if self.active:
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
                 self.opt.step_range(lo, hi, grad_scale=scale)
         self._launched = True
@@ -238,9 +262,9 @@ class BucketedExchange:
         return f"{len(self.buckets)} buckets of " + "/".join(f"{x:.0f}" for x in sizes) + " MB, exchange overlapped with backward"
 
 
-def _make_exchange(optimizer, bucketed, bucket_bytes):
+def _make_exchange(optimizer, bucketed, bucket_bytes, group=None):
     env = os.environ.get("SHINEON_BUCKETED")
-    use = (_world() > 1) if bucketed is None else bool(bucketed)
+    use = _collective() if bucketed is None else bool(bucketed)
     if env is not None and bucketed is None:
         use = env == "1"
     if not use:
@@ -248,7 +272,7 @@ def _make_exchange(optimizer, bucketed, bucket_bytes):
     if os.environ.get("SHINEON_BUCKET_MB"):
         bucket_bytes = int(float(os.environ["SHINEON_BUCKET_MB"]) * (1 << 20))
     try:
-        return BucketedExchange(optimizer, bucket_bytes)
+        return BucketedExchange(optimizer, bucket_bytes, group=group)
     except RuntimeError as e:   # no hipStreamWaitValue32 on this device: the whole-slab exchange after the graph
         logger.warning("bucketed gradient exchange unavailable (%s); falling back to GradientAllReducer", e)
         return None
@@ -282,7 +306,7 @@ def flatten_float_buffers(model):
 def broadcast_buffers(model, src=0, async_op=False):
     """DDP's broadcast_buffers=True: rank 0's BatchNorm running statistics win - one collective over the flat buffer
     tensor.  (num_batches_tracked is advanced identically on every rank, so the integer counters need no exchange.)"""
-    if _world() == 1:
+    if not _collective():
         return None
     flat = flatten_float_buffers(model)
     if flat is None:
@@ -293,7 +317,7 @@ def broadcast_buffers(model, src=0, async_op=False):
 def broadcast_parameters(model, src=0, optimizer=None):
     """Rank 0's initial weights everywhere (DDP's constructor broadcast).  With the optimizer given, the whole flat
     parameter slab travels as one message; otherwise one message per parameter."""
-    if _world() == 1:
+    if not _collective():
         return
     if optimizer is not None:
         dist.broadcast(optimizer.flat_params, src)
@@ -337,7 +361,7 @@ class TrainStep:
         self.accumulate = max(1, int(accumulate))
         self.graph = bool(graph) and self.accumulate == 1   # gradient accumulation re-enters backward: eager only
         self.overlap = bool(overlap)
-        self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(model) is not None
+        self.sync_buffers = sync_buffers and _collective() and flatten_float_buffers(model) is not None
         optimizer.zero_grad()
         self.reducer = GradientAllReducer(optimizer.flat_grads)
         self.exchange = _make_exchange(optimizer, bucketed, bucket_bytes) if self.accumulate == 1 else None
@@ -425,19 +449,42 @@ class ChainedTrainStep:
     schedule = "auto": "pipeline" on one rank; with several ranks the try-on exchange is timed once on this node and
         "pipeline" is kept only if it is cheaper than what the two-stream schedule gains (`pipeline_gain_ms`)."""
 
-    def __init__(self, warp, optw, unet, optu, sample_batch, schedule="auto", pipeline_gain_ms=None, sync_buffers=True, log=None):
+    def __init__(self, warp, optw, unet, optu, sample_batch, schedule="auto", pipeline_gain_ms=None, sync_buffers=True, log=None,
+                 bucketed=None, bucket_bytes=64 << 20):
         """pipeline_gain_ms: what the two-stream schedule saves per step on ONE rank; None = measure it here (both schedules
-        are built and replayed a few times without optimizer steps, MAX over ranks) when the choice has to be made."""
+        are built and replayed a few times without optimizer steps, MAX over ranks) when the choice has to be made.
+        bucketed: each model's gradient exchange + Adam per bucket on its own communication stream, released by signal nodes
+        inside that model's captured backward pass (BucketedExchange, as in trainer.TrainStep); None = whenever collectives
+        are issued (SHINEON_BUCKETED=0 / 1 forces it).  Measured on MI355X over a ONE-rank RCCL group
+        (SHINEON_SINGLE_RANK_GROUP=1: every collective issued, nothing on the wire; 6.66 ms/step without collectives;
+        profiles/r03_single_rank_rccl.txt):
+          one communicator for everything   whole-slab exchange after each graph 7.28 ms (+0.62, whatever the bucket count),
+                                            bucketed 8.39 ms - the warp model's buffer broadcast of step k+1 queues behind
+                                            the try-on all-reduce of step k on RCCL's stream, i.e. behind the END of the
+                                            try-on graph, and the two-stream overlap is lost
+          try-on exchange on its own        whole-slab 6.87 ms (+0.22), bucketed 6.73 ms (+0.07)   <- what is built
+          communicator (`group_u`)
+        Also tried: collectives issued on the graph streams themselves (8.31 ms); GPU_MAX_HW_QUEUES=8 (doubles the step time
+        with or without collectives)."""
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
         self.batch = sample_batch
         optw.zero_grad()
         optu.zero_grad()
-        self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads)
-        self.sync_buffers = sync_buffers and _world() > 1 and flatten_float_buffers(warp) is not None
+        # The try-on exchange gets a communicator (and with it a stream) of its OWN.  Collectives of one process group run in
+        # issue order: on a shared communicator the warp model's buffer broadcast of step k+1 queues behind the try-on
+        # all-reduce of step k - i.e. behind the END of the try-on graph - and the warp forward that should overlap that graph
+        # starts after it.
+        self.group_u = dist.new_group() if _collective() else None
+        self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads, group=self.group_u)
+        self.exw = self.exu = None
+        if schedule != "eager":
+            self.exw = _make_exchange(optw, bucketed, bucket_bytes)
+            self.exu = _make_exchange(optu, bucketed, bucket_bytes, group=self.group_u) if self.exw is not None else None
+        self.sync_buffers = sync_buffers and _collective() and flatten_float_buffers(warp) is not None
         self._pending_u = False
         self._gp = self._gw = self._gu = None
         self.exchange_ms = self.pipeline_gain_ms = None
-        auto = schedule == "auto" and _world() > 1
+        auto = schedule == "auto" and _collective()
         if schedule == "auto":
             schedule = "pipeline"
         self.schedule = schedule
@@ -448,6 +495,10 @@ class ChainedTrainStep:
             # with several ranks the try-on exchange has no other graph to hide behind in the two-stream schedule: keep that
             # schedule only if what it gains on this node (measured, not assumed) exceeds what the exchange costs (measured)
             self.exchange_ms = self._time_exchange(optu.flat_grads)
+            if self.exu is not None:
+                # bucketed: every bucket but the one completed last (the first layers') travels while the try-on backward pass
+                # is still running; what stays exposed is about one bucket's share of the whole-slab time (an estimate)
+                self.exchange_ms /= len(self.exu.buckets)
             self._build("pipeline", sample_batch)
             t_pipe = self._time_graphs()
             if pipeline_gain_ms is None:
@@ -477,19 +528,20 @@ class ChainedTrainStep:
         if schedule == "pipeline":
             from .graphs import GraphedChainedStep
 
-            self._gp = GraphedChainedStep(self.warp, self.optw, self.unet, self.optu, sample_batch)
+            self._gp = GraphedChainedStep(self.warp, self.optw, self.unet, self.optu, sample_batch, exchange_w=self.exw,
+                                          exchange_u=self.exu)
         else:
             from .graphs import GraphedTrainStep
 
-            self._gw = GraphedTrainStep(self.warp, self.optw, sample_batch)
+            self._gw = GraphedTrainStep(self.warp, self.optw, sample_batch, exchange=self.exw)
             b2 = dict(sample_batch)
             b2["cloth"] = self.warp.warped_cloth.detach()  # static output of the warp graph, consumed in place
-            self._gu = GraphedTrainStep(self.unet, self.optu, b2, alias_keys=("cloth",))
+            self._gu = GraphedTrainStep(self.unet, self.optu, b2, alias_keys=("cloth",), exchange=self.exu)
 
     @staticmethod
     def _max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        if _world() > 1:
+        if _collective():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -566,7 +618,10 @@ class ChainedTrainStep:
     def flush(self):
         """Land the try-on update that is still travelling (its exchange overlaps the next step's warp forward)."""
         if self._pending_u:
-            self.optu.step(grad_scale=self.redu.finish())
+            if self.exu is not None:
+                self.exu.finish()
+            else:
+                self.optu.step(grad_scale=self.redu.finish())
             self._pending_u = False
 
     def __call__(self, batch=None):
@@ -579,31 +634,51 @@ class ChainedTrainStep:
             if self.sync_buffers:
                 with gp.on_side():
                     broadcast_buffers(self.warp)
+            if self.exw is not None:
+                with gp.on_side():
+                    self.exw.finish()   # the previous step's warp update has landed before this warp forward
             gp.launch_warp_forward(batch)
             self.flush()
             gp.launch_tryon(batch)
+            if self.exu is not None:
+                self.exu.launch()       # per bucket: wait for its in-graph signal -> all-reduce -> Adam, on exu's own stream
             gp.launch_warp_backward()
-            with gp.on_side():
-                self.redw.start()
-                self.optw.step(grad_scale=self.redw.finish())
-            self.redu.start()
+            if self.exw is not None:
+                self.exw.launch()
+            else:
+                with gp.on_side():
+                    self.redw.start()
+                    self.optw.step(grad_scale=self.redw.finish())
+            if self.exu is None:
+                self.redu.start()
             self._pending_u = True
             return gp.result_warp, gp.result_tryon
         if self.sync_buffers:
             broadcast_buffers(self.warp)
+        if self.exw is not None:
+            self.exw.finish()
         rw = self._gw(batch)
-        self.redw.start()
+        if self.exw is not None:
+            self.exw.launch()
+        else:
+            self.redw.start()
         self.flush()
         if batch is not None:
             self._gu.load_batch({k: v for k, v in batch.items() if k != "cloth"})
         ru = self._gu()
-        self.redu.start()
+        if self.exu is not None:
+            self.exu.launch()
+        else:
+            self.redu.start()
         self._pending_u = True
-        self.optw.step(grad_scale=self.redw.finish())
+        if self.exw is None:
+            self.optw.step(grad_scale=self.redw.finish())
         return rw, ru
 
     def synchronize(self):
         self.flush()
+        if self.exw is not None:
+            self.exw.finish()
         if self._gp is not None:
             self._gp.join()
         torch.cuda.synchronize()
@@ -623,7 +698,7 @@ class MultiOptimizerStep:
         self.model, self.optimizers = model, list(optimizers)
         # Lightning's DDP wrapper re-broadcasts rank 0's buffers before EVERY forward (broadcast_buffers=True), i.e. once
         # per optimizer_idx: the per-process "syncbatch" running statistics of every SPADE stay rank 0's on all ranks
-        self.sync_buffers = bool(sync_buffers) and _world() > 1 and flatten_float_buffers(model) is not None
+        self.sync_buffers = bool(sync_buffers) and _collective() and flatten_float_buffers(model) is not None
         self.networks = list(networks) if networks is not None else model.optimizer_networks()
         if len(self.networks) != len(self.optimizers):
             raise ValueError("one network per optimizer")
@@ -633,7 +708,7 @@ class MultiOptimizerStep:
         self._frozen = [p for p in self._all if not p.requires_grad]  # e.g. the VGG of the perceptual loss: never toggled on
         self._own = [[p for p in net.parameters()] for net in self.networks]
         flats = [o.flat_grads for o in self.optimizers]  # builds the slabs now: backward then accumulates straight into them
-        self.reducers = [GradientAllReducer(f) for f in flats] if _world() > 1 else None
+        self.reducers = [GradientAllReducer(f) for f in flats] if _collective() else None
         # per optimizer: bucketed exchange overlapped with that optimizer's own backward pass (the update must have landed
         # before the next optimizer's forward, which reads the freshly updated network - Lightning's order)
         self.exchanges = None

@@ -86,3 +86,31 @@ def test_bench_multi_rank_code_path_two_ranks_on_one_gpu(extra, tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == (2 if "sams" in extra else 8)
     assert line["value"] > 0 and line["scaling"] == "weak"
     assert not [ln for ln in res[1][1].splitlines() if ln.startswith("{")]   # only rank 0 prints the JSON line
+
+
+def test_single_rank_rccl_group_runs_the_exchange_path():
+    """RCCL itself on the 1-GPU box: a one-rank nccl group (SHINEON_SINGLE_RANK_GROUP=1) with every collective of
+    trainer.TrainStep issued for real - bucketed all-reduce on the communication stream behind the in-graph signal nodes,
+    Adam per bucket - must reproduce the steps without a process group bit for bit (tests/_rccl_single_rank_child.py)."""
+    child = os.path.join(ROOT, "tests", "_rccl_single_rank_child.py")
+    p = subprocess.run([sys.executable, child, ROOT], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600, start_new_session=True)
+    assert p.returncode == 0 and "RCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-4000:]
+
+
+@pytest.mark.parametrize("extra,bucketed", [([], None), (["--config", "c3"], None), ([], "0")])
+def test_bench_over_a_single_rank_rccl_group(extra, bucketed):
+    """bench.py with the one-rank RCCL group: the N > 1 code path (broadcasts, exchange, MAX-over-ranks timing, the
+    with / without-collectives measurement behind config.exchange_exposed_ms) over the nccl backend on one GPU."""
+    import json
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-table"] + extra
+    env = dict(os.environ, SHINEON_SINGLE_RANK_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if bucketed is not None:
+        env["SHINEON_BUCKETED"] = bucketed   # c4: whole-slab exchange after each graph instead of the per-model buckets
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, start_new_session=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["config"]["exchange"] and line["config"]["exchange_exposed_ms"] is not None, line["config"]
+    assert "backend nccl" in p.stderr, p.stderr[-3000:]

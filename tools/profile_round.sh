@@ -18,10 +18,17 @@ timeout -k 5 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_c4 gaps > $OUT/${TAG}_kernel_trace_summary.txt 2>&1
 # 3. PMC passes (own runs, kernel-trace only): HBM read, HBM write per configuration; MFMA / SQ activity for the headline.
-#    Eager launches (--no-graph).  SAMS: a bounded slice (bs = 1, one step) - the full step aborted under the counters in round 2.
-for CFG in c4 c2 c3 sams; do
+#    Eager launches (--no-graph).  SAMS: the whole step and a bs = 1 slice both die under the counters (rounds 2 and 3), so its
+#    dominant kernel - the fused Winograd kernel on its most frequent layer, 128 -> 256 channels at 256x192, bs = 4 - is
+#    counted in a single-layer process (tools/one_layer.py).
+for PASS in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_pmc
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $PASS -d /tmp/prof_pmc -o r -- python3 $R/tools/one_layer.py wino 4 256 192 128 256 3 1 1 > $OUT/${TAG}_pmc_sams_layer_$PASS.log 2>&1
+  DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
+  python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_wino_fused_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
+done
+for CFG in c4 c2 c3; do
   EXTRA="--steps 3 --warmup 1 --no-graph"
-  [ $CFG = sams ] && EXTRA="--batch 1 --steps 1 --warmup 1"
   PASSES=("FETCH_SIZE" "WRITE_SIZE")
   [ $CFG = c4 ] && PASSES+=("SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE")
   for PASS in "${PASSES[@]}"; do
@@ -33,5 +40,10 @@ for CFG in c4 c2 c3 sams; do
   done
 done
 cd $R
+# 4. the exchange path over RCCL itself: a ONE-rank nccl group (every collective issued, nothing on the wire)
+for CFG in c4 c3 sams; do
+  SHINEON_SINGLE_RANK_GROUP=1 timeout -k 5 600 python3 bench.py --config $CFG --no-cpu-baseline --no-hbm-table 2> $OUT/${TAG}_single_rank_rccl_${CFG}.log | grep '^{' > $OUT/${TAG}_bench_${CFG}_single_rank_rccl.json
+  grep "exposed\|timed\|backend" $OUT/${TAG}_single_rank_rccl_${CFG}.log
+done
 for CFG in c4 c2 c3; do tail -1 $OUT/${TAG}_bench_${CFG}.json | cut -c1-300; done
 cat $OUT/${TAG}_kernel_trace_summary.txt
