@@ -1165,6 +1165,10 @@ int so_conv2d_fprop_padded(const float* x, int ldx, const float* w, const float*
                                S, pad, act, act_param, (hipStream_t)stream);
     if (r != 1) return r;
   }
+  if (C == 4 && ldx == 4 && R == 3 && S == 3 && stride == 1 && pad == 1 && Kw == Ko && !so_forced()) {  // K = 36: thin.hip
+    const int r = so_thin_expand(0, 0, x, w, bias, y, ldy, Nb, H, W, Ko, act, act_param, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = x; p.b = w; p.c = y; p.ws = ws; p.bias = bias; p.nbias = Kw;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;
@@ -1193,6 +1197,10 @@ int so_conv2d_dgrad(const float* dy, int lddy, const float* w, float* dx, int ld
                     long long ws_bytes, void* stream) {
   if ((Ko & 3) || (lddy & 3) || (C & 3) || !so_aligned16(dy) || !so_aligned16(w)) return SO_ERR_ALIGN;
   if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
+  if (Ko == 4 && lddy == 4 && R == 3 && S == 3 && stride == 1 && pad == 1 && !so_forced()) {  // four dy channels, K = 36: thin.hip
+    const int r = so_thin_expand(1, 1, dy, w, nullptr, dx, lddx, Nb, H, W, C, SO_ACT_NONE, 0.f, (hipStream_t)stream);
+    if (r != 1) return r;
+  }
   SoIgemm p = {};
   p.a = dy; p.b = w; p.c = dx; p.ws = ws;
   p.Nb = Nb; p.H = H; p.W = W; p.C = C;

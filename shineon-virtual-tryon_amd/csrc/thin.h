@@ -20,3 +20,10 @@ int so_thin_conv(int flip, const float* in, int ldin, const float* w, int wrows,
 // channels.  Same return convention as so_thin_conv.
 int so_thin_wgrad(const float* dy, int lddy, const float* x, int ldx, float* dw, int accumulate, int Nb, int H, int W,
                   int C, int Ho, int Wo, int R, int S, int pad, float* ws, long long ws_bytes, hipStream_t stream);
+
+// y[pix][0..N) = act(bias + sum_{tap, c < 4} in[pix @ tap][c] * B[tap * 4 + c][n]) for a 3x3 / stride 1 / pad 1 convolution whose
+// INPUT has exactly four channel columns (row stride 4) and N (multiple of 64, <= 256) outputs.  wmode 0: w = [n][tap][4]
+// (forward, OHWI); wmode 1: w = [4][tap][n] (OHWI with four output rows, used for the input gradient: in = dy), flip = 1
+// reverses the taps.  Same return convention as so_thin_conv.
+int so_thin_expand(int flip, int wmode, const float* in, const float* w, const float* bias, float* y, int ldy, int Nb, int H,
+                   int W, int N, int act, float act_param, hipStream_t stream);

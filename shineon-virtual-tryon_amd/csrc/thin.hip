@@ -230,7 +230,107 @@ __global__ __launch_bounds__(1024) void thin_reduce_k(const float* ws, int nslab
   }
 }
 
+// ---- four INPUT channels -> N outputs (3x3, stride 1, pad 1): K = 36 --------------------------------------------------
+// VGG conv1_1 (RGB padded to 4 -> 64) and the input gradient of the U-Net's last convolution (4 -> 128).  In the general
+// engine these are all prologue and epilogue (one or two k-steps per 64x64 tile: 73 / 58 us against ~25 us of output
+// stores).  Here a block stages the (8 + 2) x (32 + 2) pixel halo once (16 bytes per pixel), a wave owns 32-pixel row
+// segments and builds the A fragments of v_mfma_f32_32x32x2 straight from it: lane (m, kh) supplies
+// A[m][k = 2i + kh] = in[row + tap / 3][m + tap % 3][c] with tap = i / 2, c = 2 (i % 2) + kh - one ds_read_b128 per tap.
+// B[k][n] sits in LDS transposed once per block (36 x N floats) and in registers per 64-column pass; the 32x32 accumulator
+// tile is stored row by row (32 lanes = one 128-byte line of an output pixel).
+struct ThinExpand {
+  const float* in;     // [Nb][H][W][4]
+  const float* w;
+  const float* bias;   // N entries or nullptr
+  float* y;
+  int ldy, Nb, H, W, N, flip, wmode;
+  float slope;         // epilogue v > 0 ? v : v * slope  (1: none, 0: ReLU, a: LeakyReLU) - a runtime activation switch inlined
+};                     // at 32 store sites made the kernel 12 000 instructions long (instruction-cache bound: 63 us instead of 30)
+
+constexpr int TE_ROWS = 8, TE_COLS = 32, TE_HP = TE_COLS + 2;
+
+__global__ __launch_bounds__(256) void thin_expand_k(const ThinExpand p) {
+  extern __shared__ __attribute__((aligned(16))) float te_smem[];
+  f32x4* halo = reinterpret_cast<f32x4*>(te_smem);                 // [(TE_ROWS + 2)][TE_HP] pixels
+  float* wl = te_smem + (TE_ROWS + 2) * TE_HP * 4;                 // [36][N + 32]
+  const int NP = p.N + 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_w = (p.W + TE_COLS - 1) / TE_COLS, tiles_h = (p.H + TE_ROWS - 1) / TE_ROWS;
+  const int n_img = blockIdx.x / (tiles_h * tiles_w);
+  const int trem = blockIdx.x - n_img * (tiles_h * tiles_w);
+  const int h0 = (trem / tiles_w) * TE_ROWS, w0 = (trem % tiles_w) * TE_COLS;
+  for (int i = tid; i < (TE_ROWS + 2) * TE_HP; i += 256) {
+    const int h = h0 - 1 + i / TE_HP, w = w0 - 1 + i % TE_HP;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+      v = *reinterpret_cast<const f32x4*>(p.in + ((long long)(n_img * p.H + h) * p.W + w) * 4);
+    halo[i] = v;
+  }
+  // weights -> wl[k = tap * 4 + c][n]; wmode 0: w[n][tap][c] (OHWI, C = 4: forward); 1: w[c][tap][n] (OHWI with four output
+  // rows, read for the input gradient: k = tap * 4 + ko).  flip: tap -> 8 - tap (gradient taps run backwards).
+  for (int i = tid; i < 36 * p.N; i += 256) {
+    int k, n;
+    if (p.wmode == 0) { n = i / 36; k = i - n * 36; } else { const int row = i / p.N; n = i - row * p.N; k = (row % 9) * 4 + row / 9; }
+    const int tap = k >> 2, c = k & 3;
+    const int kk = ((p.flip ? 8 - tap : tap) << 2) + c;
+    wl[kk * NP + n] = p.w[i];
+  }
+  __syncthreads();
+  const int m = lane & 31, kh = lane >> 5;
+  for (int n0 = 0; n0 < p.N; n0 += 64) {
+    float b0[18], b1[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      b0[i] = wl[(2 * i + kh) * NP + n0 + m];
+      b1[i] = wl[(2 * i + kh) * NP + n0 + 32 + m];
+    }
+    const float bias0 = p.bias ? p.bias[n0 + m] : 0.f, bias1 = p.bias ? p.bias[n0 + 32 + m] : 0.f;
+    for (int row = wave; row < TE_ROWS; row += 4) {
+      const int h = h0 + row;
+      if (h >= p.H) break;
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const f32x4 v = halo[(row + tap / 3) * TE_HP + m + tap % 3];
+        const float ae = kh ? v[1] : v[0], ao = kh ? v[3] : v[2];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b0[2 * tap], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b1[2 * tap], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, b0[2 * tap + 1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, b1[2 * tap + 1], acc1, 0, 0, 0);
+      }
+      float* dst = p.y + ((long long)(n_img * p.H + h) * p.W + w0) * p.ldy + n0 + m;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int pm = (j >> 2) * 8 + kh * 4 + (j & 3);   // pixel (row of the 32x32 tile) held by accumulator register j
+        if (w0 + pm < p.W) {
+          const float v0 = acc0[j] + bias0, v1 = acc1[j] + bias1;
+          dst[(long long)pm * p.ldy] = v0 > 0.f ? v0 : v0 * p.slope;
+          dst[(long long)pm * p.ldy + 32] = v1 > 0.f ? v1 : v1 * p.slope;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int so_thin_expand(int flip, int wmode, const float* in, const float* w, const float* bias, float* y, int ldy, int Nb, int H,
+                   int W, int N, int act, float act_param, hipStream_t stream) {
+  if ((N & 63) || N > 256 || (long long)Nb * H * W >= (1 << 30)) return 1;
+  if (act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY) return 1;
+  ThinExpand p = {};
+  p.in = in; p.w = w; p.bias = bias; p.y = y; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.N = N; p.flip = flip; p.wmode = wmode;
+  p.slope = act == SO_ACT_NONE ? 1.f : (act == SO_ACT_RELU ? 0.f : act_param);
+  const size_t lds = ((size_t)(TE_ROWS + 2) * TE_HP * 4 + (size_t)36 * (N + 32)) * sizeof(float);
+  const long long M = (long long)Nb * H * W;
+  const int slot = so_prof_begin((flip ? 1 : 0) * 8 + 6, 2.0 * (double)M * N * 36.0, (int)M, N, 36, stream);
+  const dim3 grid((unsigned)((long long)Nb * so_cdiv(H, TE_ROWS) * so_cdiv(W, TE_COLS)));
+  hipLaunchKernelGGL(thin_expand_k, grid, dim3(256), lds, stream, p);
+  so_prof_end(slot, stream);
+  return SO_LAUNCH_CHECK();
+}
 
 int so_thin_conv(int flip, const float* in, int ldin, const float* w, int wrows, const float* bias, int nbias,
                  float* y, int ldy, int Nb, int OH, int OW, int IH, int IW, int IC, int R, int S, int pad, int act,
