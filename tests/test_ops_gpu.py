@@ -122,11 +122,12 @@ def test_conv2d_channel_slice_input(ops, cuda):
     assert_close(y, F.conv2d(full[:, 8:24], wt, padding=1), atol=2e-5, what="sliced conv")
 
 
+@pytest.mark.parametrize("K", [36, 40, 192])   # reduction lengths of one, two and six 32-wide k-steps (36, 40: ragged last step)
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
-def test_gemm_batched(ops, cuda, ta, tb):
+def test_gemm_batched(ops, cuda, ta, tb, K):
     from shineon_virtual_tryon_amd import lib
 
-    B, M, N, K = 3, 52, 44, 36
+    B, M, N = 3, 52, 44
     a = rnd(B, K, M, seed=9) if ta else rnd(B, M, K, seed=9)
     b = rnd(B, N, K, seed=10) if tb else rnd(B, K, N, seed=10)
     ref = torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b)
@@ -139,6 +140,28 @@ def test_gemm_batched(ops, cuda, ta, tb):
                                 torch.cuda.current_stream().cuda_stream)
     assert err == 0
     assert_close(c, ref, atol=2e-5, what=f"gemm ta={ta} tb={tb}")
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_gemm_batched_epilogue(ops, cuda, ta, tb, relu):
+    """alpha, bias, residual and ReLU in the batched GEMM's epilogue; ragged edge tiles in M and N."""
+    from shineon_virtual_tryon_amd import lib
+
+    B, M, N, K = 2, 76, 100, 64
+    a = rnd(B, K, M, seed=11) if ta else rnd(B, M, K, seed=11)
+    b = rnd(B, N, K, seed=12) if tb else rnd(B, K, N, seed=12)
+    alpha, bias, res = torch.tensor([0.37]), rnd(N, seed=13), rnd(B, M, N, seed=14)
+    ref = 0.37 * torch.bmm(a.transpose(1, 2) if ta else a, b.transpose(1, 2) if tb else b) + bias + res
+    ref = F.relu(ref) if relu else ref
+    ag, bg, alg, big, rg = (t.to(cuda) for t in (a, b, alpha, bias, res))
+    c = torch.empty(B, M, N, device=cuda)
+    ws = ops.workspace(cuda)
+    err = lib().so_gemm_batched(ta, tb, M, N, K, ag.data_ptr(), a.shape[2], a[0].numel(), bg.data_ptr(), b.shape[2], b[0].numel(),
+                                c.data_ptr(), N, M * N, B, alg.data_ptr(), big.data_ptr(), rg.data_ptr(), N, M * N, relu, 0.0,
+                                ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    assert err == 0
+    assert_close(c, ref, atol=2e-5, what=f"gemm epilogue ta={ta} tb={tb} relu={relu}")
 
 
 # ------------------------------------------------------------------------------------------------ pointwise
