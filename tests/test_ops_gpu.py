@@ -139,7 +139,8 @@ def test_gemm_batched(ops, cuda, ta, tb, K):
                                 c.data_ptr(), N, M * N, B, None, None, None, 0, 0, 0, 0.0, ws.data_ptr(), ws.numel() * 4,
                                 torch.cuda.current_stream().cuda_stream)
     assert err == 0
-    assert_close(c, ref, atol=2e-5, what=f"gemm ta={ta} tb={tb}")
+    # entries are sums of K unit-variance products (|c| ~ sqrt(K)): the fp32 summation-order difference grows with K
+    assert_close(c, ref, atol=2e-5 if K <= 40 else 1e-4, what=f"gemm ta={ta} tb={tb} K={K}")
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
