@@ -275,7 +275,9 @@ def run_sams(args, trainer, L):
                               "multiplications - executed_* is what the matrix pipe does") if dom == WINOGRAD_KEY else None,
             "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MFMA_TFLOPS,
             "traffic": sams_traffic(KEY_NAMES[dom]),
-            "traffic_source": "profiles/traffic.json [sams]: PMC passes of a bounded slice (--batch 1 --steps 1), bytes per launch",
+            "traffic_source": ("profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the kernel's most frequent "
+                               "layer of this step (128 -> 256 channels, 256x192, bs = 4) in a single-layer process "
+                               "(tools/one_layer.py; the whole step dies under the counters), bytes per launch"),
             "timing": "hip events, eager launches in the timed region", "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
             "step": {"algorithmic_gflop_per_step": gf_step, "achieved": gf_step / step_ms,
                      "frac": gf_step / step_ms / PEAK_FP32_MFMA_TFLOPS,
