@@ -37,7 +37,9 @@ extern "C" {
 /* ---- convolution / matmul on fp32 MFMA (csrc/igemm.hip) ------------------------------------------ */
 
 /* nn.Conv2d forward (unet.py:129-131,139-174; warp.py:13-31,73-85; sagan.py:12-20; vgg.py:9-23):
- * y = act(conv(x, w) + bias).  x: [Nb*H*W][C] (ldx), y: [Nb*Ho*Wo][Ko] (ldy), C % 4 == 0. */
+ * y = act(conv(x, w) + bias).  x: [Nb*H*W][C] (ldx), y: [Nb*Ho*Wo][Ko] (ldy), C % 4 == 0.
+ * act: any SO_ACT_*; none / ReLU / LeakyReLU are fused into the kernel's epilogue, the others run as a second element-wise
+ * pass over y on the same stream (same values). */
 int so_conv2d_fprop(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
                     float act_param, float* ws, long long ws_bytes, void* stream);

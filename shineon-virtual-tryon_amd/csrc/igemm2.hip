@@ -81,11 +81,19 @@ __device__ __forceinline__ void so_divmod(unsigned x, unsigned d, float inv, uns
   r = (unsigned)rem;
 }
 
+// The engine's epilogues apply none / ReLU / LeakyReLU only: the generic activation switch (erf, tanh, sin, ...) inlined at
+// every store site made the 64x64 instantiations 17 000 and the 128x128 ones 33-37 000 instructions long (2.5 min of
+// compile time, a 7.7 MB library).  so_launch applies any other activation as a second, element-wise pass over the output
+// (same fp32 values in, so the results are bit-identical to the fused form).
+__device__ __forceinline__ float so_act_epi(const SoIgemm& p, float v) {
+  return (p.act == SO_ACT_NONE || v > 0.f) ? v : (p.act == SO_ACT_RELU ? 0.f : v * p.act_param);
+}
+
 __device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long long res_off, int n) {
   if (p.alpha) v *= p.alpha[0];
   if (p.bias && n < p.nbias) v += p.bias[n];
   if (p.res) v += p.res[res_off + n];
-  return so_actf(p.act, v, p.act_param);
+  return so_act_epi(p, v);
 }
 
 // Row index of the GEMM -> element offset of that output row (and of the residual row); off < 0: skip the row.
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
                 }
                 if (p.act != SO_ACT_NONE) {
 #pragma unroll
-                  for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
+                  for (int k = 0; k < 4; ++k) v[k] = so_act_epi(p, v[k]);
                 }
                 if (p.gate) {
                   const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + off + n);
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
       if (p.res) v += *reinterpret_cast<const vec_t*>(p.res + roff + n);
       if (p.act != SO_ACT_NONE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = so_actf(p.act, v[k], p.act_param);
+        for (int k = 0; k < 4; ++k) v[k] = so_act_epi(p, v[k]);
       }
       if (p.gate) {
         const vec_t gv = *reinterpret_cast<const vec_t*>(p.gate + off + n);
@@ -959,7 +967,32 @@ static int g_autotune = 0;
 static std::map<std::array<int, 12>, SoPlan> g_plan_cache;
 
 template <int MODE, bool A_MC, bool B_MC>
+static int so_launch_inner(SoIgemm& p, long long ws_bytes, hipStream_t stream);
+
+// Activations other than none / ReLU / LeakyReLU run as a second pass over the output (see so_act_epi).
+template <int MODE, bool A_MC, bool B_MC>
 static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
+  const int act = p.act;
+  const bool deferred = act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY;
+  if (deferred) {
+    if (p.gate || (MODE != MODE_FPROP && MODE != MODE_GEMM)) return SO_ERR_SHAPE;
+    p.act = SO_ACT_NONE;
+  }
+  const int err = so_launch_inner<MODE, A_MC, B_MC>(p, ws_bytes, stream);
+  if (err || !deferred || p.M <= 0 || p.N <= 0) return err;
+  if (MODE == MODE_GEMM && p.nclass > 1 && p.sc != (long long)p.M * p.ldc) {
+    for (int b = 0; b < p.nclass; ++b) {
+      const int e = so_act_fwd(p.c + b * p.sc, p.ldc, p.c + b * p.sc, p.ldc, p.M, p.N, act, p.act_param, (void*)stream);
+      if (e) return e;
+    }
+    return 0;
+  }
+  const long long rows = (long long)p.M * (MODE == MODE_GEMM ? p.nclass : 1);
+  return so_act_fwd(p.c, p.ldc, p.c, p.ldc, rows, p.N, act, p.act_param, (void*)stream);
+}
+
+template <int MODE, bool A_MC, bool B_MC>
+static int so_launch_inner(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return 0;
   const long long ws_floats = p.ws ? ws_bytes / 4 : 0;
   if (g_force_bm || g_force_splitk || !g_autotune) return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);

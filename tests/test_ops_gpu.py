@@ -113,6 +113,27 @@ def test_conv2d_fused_relu(ops, cuda):
                     [(x, True), (wt, True), (b, True)], cuda, atol=2e-5, what="conv+relu")
 
 
+@pytest.mark.parametrize("kind,ref", [("gelu", F.gelu), ("tanh", torch.tanh), ("swish", lambda t: t * torch.sigmoid(t))])
+@pytest.mark.parametrize("case", [(2, 16, 10, 8, 24, 3, 1, 1), (2, 64, 16, 12, 4, 3, 1, 1), (4, 512, 4, 3, 512, 4, 2, 1)])
+def test_conv2d_forward_with_other_activations(ops, cuda, kind, ref, case):
+    """C-ABI contract of so_conv2d_fprop's `act`: the engine's epilogues fuse none / ReLU / LeakyReLU; every other SO_ACT_* is
+    applied as a second pass over the output (incl. the split-K and the four-output-channel paths) - same values as fused."""
+    from shineon_virtual_tryon_amd import lib
+
+    n, ci, h, w, co, k, st, p = case
+    x, wt, b = rnd(n, ci, h, w, seed=31), rnd(co, ci, k, k, seed=32, scale=(2.0 / (ci * k * k)) ** 0.5), rnd(co, seed=33, scale=0.1)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(cuda)          # NHWC
+    wg = wt.permute(0, 2, 3, 1).contiguous().to(cuda)         # OHWI
+    bg = b.to(cuda)
+    ho, wo = (h + 2 * p - k) // st + 1, (w + 2 * p - k) // st + 1
+    y = torch.empty(n, ho, wo, co, device=cuda)
+    ws = ops.workspace(cuda)
+    err = lib().so_conv2d_fprop(xg.data_ptr(), ci, wg.data_ptr(), bg.data_ptr(), y.data_ptr(), co, n, h, w, ci, co, k, k, st, p,
+                                ops.ACT_CODES[kind], 0.0, ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    assert err == 0
+    assert_close(y.permute(0, 3, 1, 2), ref(F.conv2d(x, wt, b, stride=st, padding=p)), atol=2e-5, what=f"conv+{kind} {case}")
+
+
 def test_conv2d_channel_slice_input(ops, cuda):
     """Operand that is a channel slice (pitch > C) of a wider NHWC buffer."""
     full = rnd(2, 24, 8, 6, seed=7)
