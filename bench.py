@@ -707,7 +707,9 @@ def main():
     if args.plans and rank == 0:
         log(f"saved {L.so_igemm_plans_save(args.plans.encode())} igemm plans to {args.plans}")
     if coll:
+        torch.cuda.synchronize()     # nothing of the engines' streams in flight when the communicators go away
         dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
