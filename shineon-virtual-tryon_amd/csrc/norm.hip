@@ -92,18 +92,10 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
   const unsigned g = blockIdx.y;
   Mom acc = {0.f, 0.f, 0.f};
   if (c < C) {
-    // chunking() keeps nchunk <= ~1024, i.e. at most 16-17 partials per lane: all of them are fetched before the first merge
-    // (with the loads inside the merge chain the kernel was four dependent HBM latencies long: 9-13 us).  Same merge order.
-    for (unsigned k0 = ty; k0 < nchunk; k0 += 64 * 16) {
-      float pn[16], pm[16], p2[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const unsigned k = k0 + 64u * u;
-        const float* o = part + ((size_t)g * nchunk + (k < nchunk ? k : k0)) * 3 * C;
-        pn[u] = k < nchunk ? o[c] : 0.f; pm[u] = o[C + c]; p2[u] = o[2 * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc = mom_merge(acc, Mom{pn[u], pm[u], p2[u]});
+#pragma unroll 4
+    for (unsigned k = ty; k < nchunk; k += 64) {
+      const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
+      acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
     }
   }
   sn[threadIdx.x] = acc.n; sm[threadIdx.x] = acc.mean; s2[threadIdx.x] = acc.m2;
@@ -215,16 +207,10 @@ __global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict
   const unsigned g = blockIdx.y;
   float a = 0.f, b = 0.f;
   if (c < C) {
-    for (unsigned k0 = ty; k0 < nchunk; k0 += 64 * 16) {   // all partials of a lane in flight at once, summed in the same order
-      float pa[16], pb[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const unsigned k = k0 + 64u * u;
-        const float* o = part + ((size_t)g * nchunk + (k < nchunk ? k : k0)) * 2 * C;
-        pa[u] = k < nchunk ? o[c] : 0.f; pb[u] = k < nchunk ? o[C + c] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) { a += pa[u]; b += pb[u]; }
+#pragma unroll 4
+    for (unsigned k = ty; k < nchunk; k += 64) {
+      const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
+      a += o[c]; b += o[C + c];
     }
   }
   sa[threadIdx.x] = a; sb[threadIdx.x] = b;
