@@ -10,6 +10,12 @@ synchronisation inside `training_step`; gradients must already be views of the o
 """
 import torch
 
+# Thread-local capture: with a process group alive, ProcessGroupNCCL's watchdog thread polls the events of recent collectives
+# (hipEventQuery) - under the default GLOBAL capture mode such a call from ANOTHER thread is "not permitted when stream is
+# capturing", invalidates the capture and kills the process (seen in about one start in six over a one-rank RCCL group; it
+# would hit every multi-GPU run the same way).  Only this thread's own calls need to be capture-safe.
+CAPTURE_MODE = "thread_local"
+
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, sample_batch, warmup=2, alias_keys=(), exchange=None):
@@ -32,7 +38,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
             self._step()
 
     def _step(self):
@@ -133,10 +139,10 @@ class GraphedChainedStep:
         cs = torch.cuda.Stream()
         self.g_wf, self.g_wb, self.g_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with ops.workspace_lane(8):
-            with torch.cuda.graph(self.g_wf, stream=cs):
+            with torch.cuda.graph(self.g_wf, stream=cs, capture_error_mode=CAPTURE_MODE):
                 optw.zero_grad()
                 rw = warp.training_step(sb, 0)
-            with torch.cuda.graph(self.g_wb, stream=cs):
+            with torch.cuda.graph(self.g_wb, stream=cs, capture_error_mode=CAPTURE_MODE):
                 if exw is not None:
                     exw.begin()
                 rw.minimize.backward()
@@ -149,7 +155,7 @@ class GraphedChainedStep:
         self.cloth_tryon.copy_(self.warped)
         b2 = dict(self.batch_tryon)
         b2["cloth"] = self.cloth_tryon
-        with torch.cuda.graph(self.g_u):
+        with torch.cuda.graph(self.g_u, capture_error_mode=CAPTURE_MODE):
             optu.zero_grad()
             if exu is not None:
                 exu.begin()

@@ -117,9 +117,9 @@ def test_bench_over_a_single_rank_rccl_group(extra, bucketed):
         env["SHINEON_BUCKETED"] = bucketed   # c4: whole-slab exchange after each graph instead of the per-model buckets
     p = None
     for attempt in range(2):
-        # One retry: about one run in ten of this command dies inside ProcessGroupNCCL's watchdog thread ("Exception raised from
-        # run at ProcessGroupNCCL.cpp") on this one-GPU box - seen with every exchange arrangement and before any number is
-        # printed, never in the two-rank gloo runs; the first attempt's output is kept in the failure message.
+        # One retry, kept as a belt: before the captures became thread-local (graphs.CAPTURE_MODE) about one start in six died
+        # because ProcessGroupNCCL's watchdog thread queried an event while this thread was capturing; the first attempt's
+        # output is kept in the failure message.
         first = p
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, start_new_session=True)
         if p.returncode == 0:
