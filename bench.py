@@ -45,11 +45,13 @@ KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm", "winograd_g
 KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = algorithmic (direct-convolution) FLOPs; executed = / 2.25
 WINOGRAD_KEY, WINOGRAD_FACTOR = 7, 2.25
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
-GF_PER_FRAME = {"c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": 3131.4}  # None: the MFMA launches' own 2MNK sum
+GF_PER_FRAME = {"c1": 16.8, "c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": 3131.4}  # None: the MFMA launches' own 2MNK sum
 # sams: 62 627 GF per bs = 4 x 5-frame step = the sum of 2MNK over every MFMA launch of the step as DIRECT convolutions
 # (profiles/r02_sams_bench_bs4.json; 15 657 GF at bs = 1: linear in the batch).  Since round 3 part of the 3x3 convolutions
 # run as Winograd F(2x2,3x3) and execute fewer FLOPs; the algorithmic figure stays the direct-convolution one.
 WORKLOADS = {
+    "c1": "BASELINE config 1: UnetMaskModel FORWARD (self_attn, num_attn=2, gelu; U-Net + tanh/sigmoid/mask blend) on 4x256x192 "
+          "random tensors, no backward, no loss",
     "c4": "chained warp->try-on training step (SURVEY 8d C4 at bs=4/GPU): WarpModel (GMM) fwd+bwd+Adam, then UnetMaskModel "
           "(self_attn, num_attn=2, gelu; L1+VGG19+mask loss) fwd+bwd+Adam on the warped cloth, 256x192",
     "c2": "BASELINE config 2: WarpModel (GMM feature-extract + correlation + TPS grid_sample) fwd+bwd+Adam, 256x192",
@@ -120,6 +122,34 @@ def sams_cpu_baseline(batch_size):
             "sample": f"1 warm-up + 3 timed three-optimizer SamsModel steps of the oracle at 256x192, bs={batch_size}, BOUNDED to "
                       f"n_frames_total=2 (2 instead of 5 generator passes per generation: the full step would take minutes), "
                       f"PyTorch CPU fp32: median {dt:.1f} s/step (min {times[0]:.1f}, max {times[2]:.1f})"}
+
+
+def dominant_roofline(ms, fl, by, cnt, traffic, traffic_source, timing):
+    """The `roofline` entries of the kernel with the largest summed time.  `achieved` / `frac` are what the matrix pipe
+    EXECUTES (<= 1 by construction - asserted); the direct-convolution (algorithmic) figure, which a Winograd kernel exceeds
+    by 2.25x, is kept as algorithmic_tflops / algorithmic_frac.  traffic_ratio = PMC HBM bytes per launch / algorithmic bytes
+    per launch (operands once + result once, summed by the library's profiler over this kernel's launches)."""
+    dom = max(range(NKEYS), key=lambda k: ms[k])
+    algorithmic = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    executed = algorithmic / WINOGRAD_FACTOR if dom == WINOGRAD_KEY else algorithmic
+    frac = executed / PEAK_FP32_MFMA_TFLOPS
+    assert 0.0 <= frac <= 1.0, f"roofline.frac {frac} is not a fraction: executed {executed} TFLOP/s vs peak {PEAK_FP32_MFMA_TFLOPS}"
+    alg_bytes = by[dom] / cnt[dom] if cnt[dom] and by[dom] > 0 else None
+    return dom, {
+        "bound": "mfma",
+        "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
+        "achieved": executed, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+        "achieved_note": ("EXECUTED MFMA FLOPs / kernel time" + (": the Winograd F(2x2,3x3) kernel executes 1/2.25 of the "
+                          "direct-convolution multiplications; algorithmic_* is the direct-convolution figure (2 x pixels x Ko x 9C, "
+                          "SURVEY 8d) over the same time and may exceed the peak of a direct kernel" if dom == WINOGRAD_KEY else
+                          " (= algorithmic FLOPs for this kernel)")),
+        "algorithmic_tflops": algorithmic, "algorithmic_frac": algorithmic / PEAK_FP32_MFMA_TFLOPS,
+        "executed_tflops": executed, "executed_frac": frac,
+        "traffic": traffic, "traffic_source": traffic_source if traffic else None,
+        "algorithmic_bytes": alg_bytes,
+        "traffic_ratio": (traffic / alg_bytes) if traffic and alg_bytes else None,
+        "timing": timing, "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+    }
 
 
 def sams_traffic(key):
@@ -241,14 +271,18 @@ def run_sams(args, trainer, L):
     ms = (ctypes.c_float * NKEYS)()
     fl = (ctypes.c_float * NKEYS)()
     cnt = (ctypes.c_int * NKEYS)()
-    L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
+    by = (ctypes.c_double * NKEYS)()
+    L.so_prof_collect_bytes(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt), ctypes.addressof(by))
     if rank != 0:
         return
     kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / args.steps,
                               "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(NKEYS) if cnt[k] > 0}
-    dom = max(range(NKEYS), key=lambda k: ms[k])
-    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-    executed = achieved / WINOGRAD_FACTOR if dom == WINOGRAD_KEY else achieved
+    dom0 = max(range(NKEYS), key=lambda k: ms[k])
+    dom, roof = dominant_roofline(
+        ms, fl, by, cnt, sams_traffic(KEY_NAMES[dom0]),
+        "profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the kernel's most frequent layer of this step "
+        "(128 -> 256 channels, 256x192, bs = 4) in a single-layer process (tools/one_layer.py; the whole step dies under the "
+        "counters), bytes per launch", "hip events, eager launches in the timed region")
     for k_ in kernels.values():
         k_["executed_tflops"] = k_["tflops"]
     if "winograd_fused" in kernels:
@@ -267,18 +301,7 @@ def run_sams(args, trainer, L):
                    "parameters_M": [round(n / 1e6, 2) for n in nparams],
                    "peak_hbm_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         "roofline": {
-            "bound": "mfma",
-            "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
-            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-            "achieved_note": ("ALGORITHMIC (direct-convolution) FLOPs / kernel time; Winograd F(2x2,3x3) needs 1/2.25 of those "
-                              "multiplications - executed_* is what the matrix pipe does") if dom == WINOGRAD_KEY else None,
-            "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": sams_traffic(KEY_NAMES[dom]),
-            "traffic_source": ("profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the kernel's most frequent "
-                               "layer of this step (128 -> 256 channels, 256x192, bs = 4) in a single-layer process "
-                               "(tools/one_layer.py; the whole step dies under the counters), bytes per launch"),
-            "timing": "hip events, eager launches in the timed region", "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+            **roof,
             "step": {"algorithmic_gflop_per_step": gf_step, "achieved": gf_step / step_ms,
                      "frac": gf_step / step_ms / PEAK_FP32_MFMA_TFLOPS,
                      "note": "direct-convolution FLOPs of the step (sum of 2MNK over its MFMA launches before Winograd, "
@@ -296,6 +319,117 @@ def run_sams(args, trainer, L):
         out["cpu_baseline"] = sams_cpu_baseline(args.batch)
     print(json.dumps(flatten_roofline(out)), flush=True)
 
+
+
+def run_c1(args, trainer, L):
+    """--config c1 (BASELINE config 1): UnetMaskModel.forward alone - the reference's own CPU-runnable case - on the GPU (one
+    hipGraph of the forward pass, replayed) with the oracle's forward timed beside it on this host's cores."""
+    from oracle import shineon_oracle as oracle
+    from oracle.procedural import procedural_state_dict, shapes_of
+
+    rank, world, dev = trainer.rank, trainer.world, trainer.device
+    model = UnetMaskModel(hparams(person_inputs=["agnostic", "densepose"])).to(dev).train()
+    batch = synthetic_batch(args.batch, dev, seed=420, start=rank * args.batch)
+    person = torch.cat([batch["agnostic"], batch["densepose"]], 1)
+    cloth = batch["cloth"]
+    with torch.no_grad():
+        for _ in range(2):
+            out = model(person, cloth)   # plans measured, scratch sized
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model(person, cloth)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = model(person, cloth)
+
+        def step():
+            if graph is not None:
+                graph.replay()
+            else:
+                model(person, cloth)
+
+        def fence():
+            torch.cuda.synchronize()
+            if so_trainer._collective():
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if so_trainer._collective():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        prof_steps = min(args.steps, 5)
+        L.so_prof_enable(1)
+        for _ in range(prof_steps):
+            model(person, cloth)
+        fence()
+        L.so_prof_enable(0)
+    ms = (ctypes.c_float * NKEYS)()
+    fl = (ctypes.c_float * NKEYS)()
+    cnt = (ctypes.c_int * NKEYS)()
+    by = (ctypes.c_double * NKEYS)()
+    L.so_prof_collect_bytes(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt), ctypes.addressof(by))
+    if rank != 0:
+        return
+    kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / prof_steps,
+                              "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(NKEYS) if cnt[k] > 0}
+    dom, roof = dominant_roofline(ms, fl, by, cnt, None, None,
+                                  f"hip events on the same kernels launched eagerly for {prof_steps} passes right after the timed region")
+    step_ms = 1e3 * elapsed / args.steps
+    gf_step = GF_PER_FRAME["c1"] * args.batch
+    out = {
+        "metric": "try-on frames/sec (UnetMaskModel forward only) at 256x192 bs=4",
+        "value": world * args.batch * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": WORKLOADS["c1"], "config": "c1", "launch": "eager" if graph is None else "one hipGraph (forward)",
+                   "batch_per_gpu": args.batch, "global_batch": world * args.batch, "frames_per_sample": 1, "parallelism": f"dp{world}",
+                   "step_api": "shineon_virtual_tryon_amd.unet_mask_model.UnetMaskModel.forward"},
+        "roofline": {**roof,
+                     "step": {"algorithmic_gflop_per_step": gf_step, "achieved": gf_step / step_ms,
+                              "frac": gf_step / step_ms / PEAK_FP32_MFMA_TFLOPS,
+                              "note": "whole forward pass incl. every non-GEMM kernel: algorithmic FLOPs (SURVEY 8d: 16.8 GF/frame) / "
+                                      "measured time / fp32-MFMA peak"},
+                     "mfma_ms_per_step": sum(ms) / prof_steps, "mfma_time_frac_of_step": sum(ms) / prof_steps / step_ms},
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(usable_cores())
+        sd = procedural_state_dict(shapes_of(model.state_dict()))
+        cb = synthetic_batch(args.batch, "cpu", seed=420)
+        cperson, ccloth = torch.cat([cb["agnostic"], cb["densepose"]], 1), cb["cloth"]
+        uhp = dict(n_frames_total=1, self_attn=True, num_attn=2, activation="gelu", flow_warp=False)
+        times = []
+        with torch.no_grad():
+            for _ in range(2):
+                oracle.unet_mask_forward(sd, cperson, ccloth, uhp)
+            t_begin = time.perf_counter()
+            while len(times) < max(args.cpu_iters, 5) and (len(times) < 3 or time.perf_counter() - t_begin < 45.0):
+                t0 = time.perf_counter()
+                oracle.unet_mask_forward(sd, cperson, ccloth, uhp)
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        out["cpu_baseline"] = {"value": args.batch / med, "unit": "frames/s", "cores": torch.get_num_threads(), "cpu": cpu_model(),
+                               "kind": "port",
+                               "sample": f"2 warm-up + {len(times)} timed UnetMaskModel forward passes of the oracle (bs={args.batch}, "
+                                         f"256x192) with PyTorch CPU fp32, median {med * 1e3:.0f} ms (min {times[0] * 1e3:.0f}, "
+                                         f"max {times[-1] * 1e3:.0f})"}
+    print(json.dumps(flatten_roofline(out)), flush=True)
 
 
 def hparams(**kw):
@@ -470,8 +604,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU (BASELINE: 4)")
-    ap.add_argument("--config", choices=("c4", "c2", "c3", "c5", "sams"), default="c4",
-                    help="c4: chained warp->try-on step (headline); c2: WarpModel alone; c3: UnetMaskModel alone; "
+    ap.add_argument("--config", choices=("c4", "c1", "c2", "c3", "c5", "sams"), default="c4",
+                    help="c4: chained warp->try-on step (headline); c1: UnetMaskModel forward only (BASELINE config 1, GPU + CPU leg); "
+                         "c2: WarpModel alone; c3: UnetMaskModel alone; "
                          "c5: 5-frame flow_warp UnetMaskModel, bs=2 sequences (frames/s counts bs x 5 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
@@ -509,6 +644,12 @@ def main():
         if "--steps" not in sys.argv:
             args.steps, args.warmup = 3, 1
         run_sams(args, trainer, L)
+        if coll:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if cfg == "c1":
+        run_c1(args, trainer, L)
         if coll:
             dist.barrier()
             dist.destroy_process_group()
@@ -624,20 +765,25 @@ def main():
     ms = (ctypes.c_float * NKEYS)()
     fl = (ctypes.c_float * NKEYS)()
     cnt = (ctypes.c_int * NKEYS)()
-    L.so_prof_collect(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt))
+    by = (ctypes.c_double * NKEYS)()
+    L.so_prof_collect_bytes(ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(cnt), ctypes.addressof(by))
 
     if rank == 0:
         kernels = {KEY_NAMES[k]: {"launches": cnt[k], "avg_us": 1e3 * ms[k] / cnt[k], "total_ms_per_step": ms[k] / prof_steps,
-                                  "tflops": fl[k] / (ms[k] * 1e-3) / 1e12}
+                                  "tflops": fl[k] / (ms[k] * 1e-3) / 1e12,
+                                  "algorithmic_bytes_per_launch": (by[k] / cnt[k]) if by[k] > 0 else None}
                    for k in range(NKEYS) if cnt[k] > 0}
-        dom = max(range(NKEYS), key=lambda k: ms[k])
+        dom0 = max(range(NKEYS), key=lambda k: ms[k])
         traffic = None  # HBM bytes per launch of the dominant instantiation, from the committed PMC passes
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             sect = json.load(open(tpath)).get(cfg, {})   # (the PMC passes see kernel symbols: Winograd-domain GEMMs = gemm_*)
-            traffic = (sect.get(KEY_NAMES[dom]) or sect.get(KEY_NAMES[dom].replace("winograd_gemm_", "gemm_"), {})).get("hbm_bytes_per_launch")
-        achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-        executed = achieved / WINOGRAD_FACTOR if dom == WINOGRAD_KEY else achieved
+            traffic = (sect.get(KEY_NAMES[dom0]) or sect.get(KEY_NAMES[dom0].replace("winograd_gemm_", "gemm_"), {})).get("hbm_bytes_per_launch")
+        dom, roof = dominant_roofline(
+            ms, fl, by, cnt, traffic,
+            "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)",
+            ("hip events, eager launches in the timed region" if args.no_graph else
+             f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the graph-replayed timed region"))
         for k_ in kernels.values():
             k_["executed_tflops"] = k_["tflops"]
         if "winograd_fused" in kernels:
@@ -673,21 +819,7 @@ def main():
                        "pipeline_gain_ms": getattr(engine, "pipeline_gain_ms", None) if cfg == "c4" else None,
                        "exchange_probe_ms": getattr(engine, "exchange_ms", None) if cfg == "c4" else None},
             "roofline": {
-                "bound": "mfma",
-                "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else
-                           f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
-                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                "achieved_note": ("ALGORITHMIC FLOPs of the convolutions (2 x pixels x Ko x 9C, SURVEY 8d) / kernel time; "
-                                  "Winograd F(2x2,3x3) needs 1/2.25 of those multiplications, so this may exceed the peak of a "
-                                  "direct kernel - executed_* is what the matrix pipe actually does") if dom == WINOGRAD_KEY else None,
-                "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                  "bytes per launch)" if traffic else None,
-                "timing": ("hip events, eager launches in the timed region" if args.no_graph else
-                           f"hip events on the same kernels launched eagerly for {prof_steps} steps right after the "
-                           "graph-replayed timed region"),
-                "avg_launch_us": 1e3 * ms[dom] / max(1, cnt[dom]),
+                **roof,
                 "step": {"algorithmic_gflop_per_step": gf_step, "achieved": step_tflops,
                          "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                          "note": "whole step incl. every non-GEMM kernel, Adam and launch gaps: algorithmic FLOPs (SURVEY 8d) / "

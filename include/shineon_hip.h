@@ -145,6 +145,10 @@ int so_igemm_plans_load(const char* path);
  * Winograd kernel: the direct convolution's), launch count.  Returns the number of launches collected and clears the list. */
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
+/* the same + out_bytes[k] (HOST array of 40 doubles; may be NULL): summed ALGORITHMIC HBM bytes of the launches under key k -
+ * every operand read once and the result written once (convolutions: input-side tensor + output-side tensor + filter;
+ * batched GEMM: A + B + C); bench.py's roofline.traffic / algorithmic_bytes ratio divides the PMC bytes by this */
+int so_prof_collect_bytes(float* out_ms, float* out_flops, int* out_count, double* out_bytes);
 
 /* ---- normalisation (csrc/norm.hip) ---------------------------------------------------------------- */
 
@@ -273,6 +277,14 @@ int so_signal_can_wait(void);
 int so_counter_bump(void* counter, void* stream);
 int so_signal_store(void* flag, const void* counter, int system_scope, void* stream);
 int so_stream_wait_ge(void* flag, int value, int mode, void* stream);
+/* The polling wait with an escape (no unbounded device spin): `words` = so_hostwords_alloc() - two zeroed 32-bit words of
+ * pinned, device-mapped host memory, valid on host and device: words[0] = abort request (the host stores 1 on any exception
+ * path; no stream needed), words[1] = status written by the waiter (1 = aborted, 2 = `max_ticks` ticks of the 100 MHz wall
+ * clock passed).  On either the waiter RETURNS - the stream and every peer inside the collective queued behind it move on -
+ * and the host raises when it next looks at words[1] (BucketedExchange.finish). */
+int so_stream_wait_ge_bounded(void* flag, int value, void* words, long long max_ticks, void* stream);
+long long so_hostwords_alloc(void);
+int so_hostwords_free(long long ptr);
 
 /* ---- geometric matching + attention row kernels (csrc/gmm.hip) ------------------------------------ */
 

@@ -28,6 +28,7 @@ _CTYPES = {
     "const double*": ctypes.c_void_p,
     "const void*": ctypes.c_void_p,
     "float*": ctypes.c_void_p,
+    "double*": ctypes.c_void_p,
     "int*": ctypes.c_void_p,
     "void*": ctypes.c_void_p,
     "const char*": ctypes.c_char_p,
@@ -50,7 +51,7 @@ def prototypes(header_path=HEADER_PATH):
             a = re.sub(r"\s+", " ", a)
             if a == "void":
                 continue
-            mm = re.match(r"(const float\*|const double\*|const void\*|const char\*|float\*|int\*|void\*|long long|int|float)\s*\w*$", a)
+            mm = re.match(r"(const float\*|const double\*|const void\*|const char\*|float\*|double\*|int\*|void\*|long long|int|float)\s*\w*$", a)
             if not mm:
                 raise RuntimeError(f"cannot parse argument '{a}' of {name}")
             argtypes.append(_CTYPES[mm.group(1)])

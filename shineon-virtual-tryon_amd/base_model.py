@@ -45,8 +45,12 @@ class BaseModel(LightningModule, abc.ABC):
             self.val_visualization_batch = None
 
     def override_hparams(self, hparams):
-        """Re-apply non-architectural flags after a checkpoint load (base_model.py:76-89)."""
+        """Re-apply non-architectural flags after a checkpoint load (base_model.py:76-89).
+        One deliberate difference: `is_train` follows the NEW options.  The reference keeps the value stored in the checkpoint
+        (True for anything train.py wrote), so `python test.py --checkpoint <train checkpoint>` never sets test_results_dir and
+        its test_step dies on the missing attribute (the TODO at train.py:41-44); here the documented test command lines run."""
         self.hparams = hparams
+        self.is_train = bool(getattr(hparams, "is_train", self.is_train))
         if not self.is_train:
             ckpt_name = osp.basename(hparams.checkpoint)
             self.test_results_dir = osp.join(hparams.result_dir, hparams.name, ckpt_name, hparams.datamode)

@@ -744,8 +744,28 @@ __global__ void signal_store_k(unsigned* flag, const unsigned* counter, int syst
   }
 }
 
-__global__ void wait_flag_k(const unsigned* flag, unsigned value) {
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) __builtin_amdgcn_s_sleep(64);
+// Bounded: besides the signal word the lane looks, every 64th poll, at a host-pinned abort word (the host sets it on any
+// exception path, without needing a stream) and at the 100 MHz wall clock.  On abort / deadline it stores an error code into
+// the host-pinned status word and RETURNS, so that the communication stream - and, with several ranks, every peer inside
+// the collective queued behind this wait - moves on instead of hanging; the host raises at the next finish().
+__global__ void wait_flag_k(const unsigned* flag, unsigned value, const unsigned* abort_word, unsigned* status,
+                            unsigned long long max_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned polls = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+    __builtin_amdgcn_s_sleep(64);
+    if ((++polls & 63u) == 0u && status != nullptr) {
+      unsigned code = 0u;
+      if (abort_word != nullptr && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+        code = 1u;   // SO_WAIT_ABORTED
+      else if ((unsigned long long)wall_clock64() - t0 > max_ticks)
+        code = 2u;   // SO_WAIT_DEADLINE
+      if (code) {
+        __hip_atomic_store(status, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
@@ -1095,15 +1115,35 @@ int so_signal_store(void* flag, const void* counter, int system_scope, void* str
 }
 
 // mode 0: hipStreamWaitValue32 (command-processor wait, no CU occupied).  mode 1: a one-lane kernel that polls the word with
-// system-scope relaxed loads and s_sleep between polls (one wave slot on one CU, nothing for the command processor to do).
+// AGENT-scope relaxed loads (the matching so_signal_store releases at agent scope) and s_sleep between polls (one wave slot on one CU, nothing for the command processor to do).
 // Measured on MI355X (bench.py --config c3, one rank): with the CP wait queued right after the graph launch every one of
 // the ~500 kernels of the step dispatches ~1.5 us later (6.64 vs 5.87 ms/step) - the command processor polls the word for
 // the whole step; the spin kernel does not touch the dispatch path.
 int so_stream_wait_ge(void* flag, int value, int mode, void* stream) {
   if (mode == 0)
     return (int)hipStreamWaitValue32((hipStream_t)stream, flag, (uint32_t)value, hipStreamWaitValueGte, 0xFFFFFFFFu);
-  hipLaunchKernelGGL(wait_flag_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned)value);
+  hipLaunchKernelGGL(wait_flag_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned)value,
+                     (const unsigned*)nullptr, (unsigned*)nullptr, 0ull);
   return SO_LAUNCH_CHECK();
 }
+
+// The polling wait with an escape: `words` = so_hostwords_alloc(): words[0] abort request (host writes 1), words[1] status
+// (kernel writes 1 = aborted, 2 = deadline of `max_ticks` 100 MHz ticks passed).
+int so_stream_wait_ge_bounded(void* flag, int value, void* words, long long max_ticks, void* stream) {
+  if (!words || max_ticks <= 0) return SO_ERR_SHAPE;
+  hipLaunchKernelGGL(wait_flag_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)flag, (unsigned)value,
+                     (const unsigned*)words, (unsigned*)words + 1, (unsigned long long)max_ticks);
+  return SO_LAUNCH_CHECK();
+}
+
+// two zeroed 32-bit words of pinned, device-mapped, coherent host memory; the returned address is valid on host and device
+long long so_hostwords_alloc(void) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return 0;
+  for (int i = 0; i < 16; ++i) ((volatile unsigned*)p)[i] = 0u;
+  return (long long)(uintptr_t)p;
+}
+
+int so_hostwords_free(long long ptr) { return ptr ? (int)hipHostFree((void*)(uintptr_t)ptr) : 0; }
 
 }  // extern "C"

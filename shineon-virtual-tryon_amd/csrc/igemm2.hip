@@ -851,6 +851,7 @@ struct SoProfRec {
   hipEvent_t e0, e1;
   int key;  // MODE * 8 + tile index (0: 64x64, 1: 128x64, 2: 64x128, 3: 128x128, 4/5: 8-wave tiles, 6: thin.hip)
   double flops;
+  double bytes;  // algorithmic HBM bytes of the launch: every operand read once + the result written once (0: not stated)
   int M, N, K, nclass, splitk;
 };
 static const char* g_prof_dump_path = nullptr;
@@ -877,10 +878,15 @@ int so_prof_begin(int key, double flops, int M, int N, int K, hipStream_t stream
   if (!rec.e0 || !rec.e1) return -1;  // no events available: this launch is simply not timed
   rec.key = key;
   rec.flops = flops;
+  rec.bytes = 0.0;
   rec.M = M; rec.N = N; rec.K = K; rec.nclass = 1; rec.splitk = 1;
   (void)hipEventRecord(rec.e0, stream);
   g_prof.push_back(rec);
   return (int)g_prof.size() - 1;
+}
+
+void so_prof_bytes(int slot, double bytes) {
+  if (slot >= 0 && slot < (int)g_prof.size()) g_prof[slot].bytes = bytes;
 }
 
 void so_prof_end(int slot, hipStream_t stream) {
@@ -915,6 +921,11 @@ static int so_launch_tile(const SoIgemm& p, hipStream_t stream) {
     // key group (4), so that they are not averaged with the ~10 us attention GEMMs that share the 64x64 instantiation
     if (MODE == MODE_GEMM && p.nclass >= 16) rec.key += 8;
     rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
+    // convolution modes (fprop / dgrad / wgrad alike): the input-side tensor, the output-side tensor and the filter, each
+    // touched once; batched GEMM: A, B and C of every matrix
+    rec.bytes = MODE == MODE_GEMM
+                    ? 4.0 * p.nclass * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N)
+                    : 4.0 * ((double)p.Nb * p.H * p.W * p.C + (double)p.Nb * p.Ho * p.Wo * p.Ko + (double)p.Ko * p.R * p.S * p.C);
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
   }
@@ -1160,8 +1171,14 @@ void so_prof_enable(int on) { g_prof_on = on != 0; }
 // wgrad, gemm, Winograd-domain gemm):
 // out_ms[k] = summed kernel time in ms, out_flops[k] = summed algorithmic FLOPs, out_count[k] = launches.
 // Clears the record list.  Returns the number of launches collected.
+int so_prof_collect_bytes(float* out_ms, float* out_flops, int* out_count, double* out_bytes);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
-  for (int k = 0; k < 40; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; }
+  return so_prof_collect_bytes(out_ms, out_flops, out_count, nullptr);
+}
+
+// + out_bytes[k] = summed algorithmic HBM bytes (operands once + result once) of the launches under key k (may be null)
+int so_prof_collect_bytes(float* out_ms, float* out_flops, int* out_count, double* out_bytes) {
+  for (int k = 0; k < 40; ++k) { out_ms[k] = 0.f; out_flops[k] = 0.f; out_count[k] = 0; if (out_bytes) out_bytes[k] = 0.0; }
   int n = 0;
   FILE* dump = nullptr;
   if (const char* path = getenv("SO_PROF_DUMP")) dump = fopen(path, "w");
@@ -1174,6 +1191,7 @@ int so_prof_collect(float* out_ms, float* out_flops, int* out_count) {
                 ms > 0 ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
       out_ms[r.key] += ms;
       out_flops[r.key] += (float)r.flops;
+      if (out_bytes) out_bytes[r.key] += r.bytes;
       out_count[r.key] += 1;
       ++n;
     }

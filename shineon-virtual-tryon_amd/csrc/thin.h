@@ -7,6 +7,7 @@
 // a slot index (or -1 when timing is off) to hand to so_prof_end.  Defined in igemm2.hip.
 int so_prof_begin(int key, double flops, int M, int N, int K, hipStream_t stream);
 void so_prof_end(int slot, hipStream_t stream);
+void so_prof_bytes(int slot, double bytes);  // algorithmic HBM bytes of the launch recorded under `slot` (operands + result once)
 
 // y[pix][0..3] = act(bias + sum_{r,s,c} in[pix @ (r,s)][c] * w[j][(r*S+s)*IC + c]) for a stride-1 convolution whose
 // OUTPUT has four channel columns.  flip = 0: forward conv (in = x, tap offset r - pad); flip = 1: input gradient

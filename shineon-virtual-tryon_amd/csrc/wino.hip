@@ -828,6 +828,8 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   // (16 instead of 36 multiplications per 2x2 tile and channel pair) - bench.py reports both.
   const int slot = so_prof_begin(0 * 8 + 7, 2.0 * (double)Nb * H * W * (double)Ko * 9.0 * (double)C, Nb * H * W, Ko, 9 * C,
                                  (hipStream_t)stream);
+  // algorithmic bytes: x and y once + the 16 Winograd-domain filter planes this kernel reads (16 / 9 of the 3x3 filter)
+  so_prof_bytes(slot, 4.0 * ((double)Nb * H * W * ((double)C + (double)Ko) + 16.0 * (double)C * (double)Ko));
   if (nkg == 2)
     hipLaunchKernelGGL(wino_fused_k<2>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   else

@@ -107,6 +107,56 @@ def synthetic_batch(batch_size, device, height=256, width=192, n_frames=1, seed=
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 
+class _FileBackedDataset(Dataset):
+    """Command-line surface of the reference's file-backed datasets (datasets/tryon_dataset.py:63-96,
+    n_frames_interface.py:33-52, vvt_dataset.py:22-31, viton_dataset.py:14-18, mpv_dataset.py:15-18) so that its documented
+    command lines (docs/2_inference.md, docs/3_train.md) parse and resolve here.  Reading those folder layouts is outside
+    the hot path (the boundary is the batch dict): with the reference's `datasets` package on sys.path it is used
+    as is, otherwise constructing one of these raises."""
+
+    extra_flags = ()
+
+    def __init__(self, opt, *a, **k):
+        raise NotImplementedError(
+            f"--dataset {getattr(opt, 'dataset', '?')} reads the reference's folder layout: put the reference's datasets/ "
+            "package on sys.path (it is used unchanged - it produces the batch dict this package consumes), or use "
+            "--dataset synthetic")
+
+    @classmethod
+    def modify_commandline_options(cls, parser, is_train):
+        parser.add_argument("--val_fraction", type=float, default=0.01 if is_train else 0)
+        parser.add_argument("--cloth_mask_threshold", type=int, default=240)
+        parser.add_argument("--image_scale", type=float, default=1)
+        parser.add_argument("--fine_width", type=int, default=192)
+        parser.add_argument("--fine_height", type=int, default=256)
+        parser.add_argument("--radius", type=int, default=5)
+        parser.add_argument("--visualize_flow", action="store_true")
+        parser.add_argument("--n_frames_total", type=int, default=1, metavar="N")
+        parser.add_argument("--n_frames_now", type=int, default=None, metavar="N")
+        for flag, kw in cls.extra_flags:
+            parser.add_argument(flag, **kw)
+        return parser
+
+
+class _VVT(_FileBackedDataset):
+    extra_flags = (("--vvt_dataroot", dict(default="/data_hdd/fw_gan_vvt")), ("--warp_cloth_dir", dict(default=None)))
+
+
+class _Viton(_FileBackedDataset):
+    extra_flags = (("--viton_dataroot", dict(default="data")), ("--data_list", dict(default="train_pairs.txt")))
+
+
+class _MPV(_FileBackedDataset):
+    extra_flags = (("--mpv_dataroot", dict(default="/data_hdd/mpv_competition")),)
+
+
+class _VitonVvtMpv(_FileBackedDataset):
+    extra_flags = _Viton.extra_flags + _VVT.extra_flags + _MPV.extra_flags
+
+
+_FILE_BACKED = {"vvt": _VVT, "viton": _Viton, "mpv": _MPV, "viton_vvt_mpv": _VitonVvtMpv}
+
+
 def find_dataset_using_name(name):
     if name == "synthetic":
         return SyntheticDataset
@@ -115,6 +165,8 @@ def find_dataset_using_name(name):
 
         return ref_datasets.find_dataset_using_name(name)
     except Exception as e:  # noqa: BLE001
+        if name in _FILE_BACKED:   # flags parse; construction explains what is needed
+            return _FILE_BACKED[name]
         raise NotImplementedError(
             f"dataset '{name}' needs the reference's datasets/ package on sys.path ({type(e).__name__}: {e}); "
             "use --dataset synthetic otherwise"

@@ -13,6 +13,7 @@ The step itself lives in two small engines that bench.py and Trainer.fit share:
   ChainedTrainStep  the warp -> try-on pair of SURVEY 8d C4: three hipGraphs on two streams (graphs.GraphedChainedStep) or two
                     sequential graphs, both gradient exchanges hidden behind the other model's compute.
 """
+import ctypes
 import logging
 import os
 import os.path as osp
@@ -39,7 +40,8 @@ def init_distributed(backend=None):
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         torch.cuda.set_device(int(os.environ.get("SHINEON_LOCAL_DEVICE", "0")))
-        dist.init_process_group(backend=backend or "nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        dist.init_process_group(backend=backend or "nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                **_group_timeout())
         return 0, 1
     if world <= 1 or dist.is_initialized():
         return dist.get_rank() if dist.is_initialized() else 0, max(world, 1)
@@ -48,13 +50,17 @@ def init_distributed(backend=None):
     backend = backend or os.environ.get("SHINEON_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("SHINEON_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
-    kw = {}
-    if os.environ.get("SHINEON_DIST_TIMEOUT_S"):  # tests: fail a broken rendezvous in minutes, not in the 30-minute default
-        import datetime
-
-        kw["timeout"] = datetime.timedelta(seconds=float(os.environ["SHINEON_DIST_TIMEOUT_S"]))
-    dist.init_process_group(backend=backend, **kw)
+    dist.init_process_group(backend=backend, **_group_timeout())
     return dist.get_rank(), dist.get_world_size()
+
+
+def _group_timeout():
+    """SHINEON_DIST_TIMEOUT_S: fail a broken rendezvous / a collective nobody joins in minutes, not in the 10-30 minute default."""
+    if not os.environ.get("SHINEON_DIST_TIMEOUT_S"):
+        return {}
+    import datetime
+
+    return {"timeout": datetime.timedelta(seconds=float(os.environ["SHINEON_DIST_TIMEOUT_S"]))}
 
 
 def _world():
@@ -129,7 +135,18 @@ class BucketedExchange:
 
     Safety: a bucket's parameters are read for the last time by the input-gradient kernels launched before its signal node
     (same stream), its gradients are written for the last time there too; buckets are disjoint slab ranges.  finish() makes
-    the compute stream wait for the communication stream before the next forward."""
+    the compute stream wait for the communication stream before the next forward.
+
+    Invariants that are CHECKED, not assumed:
+      * every pass reports each parameter exactly as often as the calibration pass did (end(): a parameter reporting MORE
+        often would have released its bucket in mid-backward - partial gradients reduced, weights rewritten under dgrad
+        kernels that still read them; under capture that would be baked into every replay).  A mismatch raises; call
+        recalibrate() when the model's pass structure changes on purpose;
+      * launch() is only legal after the step holding the matching signal nodes has been enqueued (begin() or note_replay()
+        since the previous launch): the default wait is a polling kernel on a stream that shares hardware queues with the
+        compute streams - queued AHEAD of its producer it would spin with nothing behind it;
+      * the polling wait is bounded (so_stream_wait_ge_bounded): abort() - called by the engines on any exception path - or
+        the deadline (SHINEON_WAIT_DEADLINE_S, default 60 s) makes it return with a status the next finish() raises on."""
 
     def __init__(self, optimizer, bucket_bytes=64 << 20, group=None):
         from ._lib import check, lib
@@ -168,6 +185,13 @@ class BucketedExchange:
         self.step_no = 0
         self._launched = False
         self._armed = False
+        self._launched_step = 0     # step_no of the last launch(): launch() must follow a newly enqueued step
+        # [abort request, waiter status]: pinned host words the polling kernels read / write (include/shineon_hip.h)
+        self.words = self.L.so_hostwords_alloc()
+        if not self.words:
+            raise RuntimeError("hipHostMalloc of the abort / status words failed")
+        self._words = (ctypes.c_uint32 * 2).from_address(self.words)
+        self.deadline_ticks = int(float(os.environ.get("SHINEON_WAIT_DEADLINE_S", "60")) * 1e8)   # 100 MHz wall clock
         # 1 = one-lane polling kernel (default), 0 = hipStreamWaitValue32: the command-processor wait slows the dispatch of
         # every kernel of the step it waits through (6.64 vs 5.87 ms/step measured on c3), the polling kernel does not
         self.wait_mode = int(os.environ.get("SHINEON_WAIT_MODE", "1"))
@@ -176,8 +200,28 @@ class BucketedExchange:
         try:
             for f in self.flags:
                 self.L.so_signal_free(f)
+            if getattr(self, "words", 0):
+                self._words = None
+                self.L.so_hostwords_free(self.words)
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+    def abort(self):
+        """Exception path: release every polling wait that is queued or running (they return within ~64 polls) so that neither
+        this process nor a peer inside the collective behind the wait hangs.  The exchange is unusable afterwards."""
+        if self._words is not None:
+            self._words[0] = 1
+
+    def check_status(self):
+        code = int(self._words[1]) if self._words is not None else 0
+        if code:
+            raise RuntimeError("gradient-bucket wait " + {1: "was aborted", 2: "passed its deadline (SHINEON_WAIT_DEADLINE_S): a bucket's "
+                               "signal node never ran"}.get(code, f"failed with status {code}") + "; the step's gradients are incomplete")
+
+    def recalibrate(self):
+        """The model's pass structure changed on purpose (another number of generator passes, a weight now shared): the next
+        begin() / end() pair is a calibration pass again (buckets released at end())."""
+        self.expected = self.order = None
 
     # ---- while the backward pass is being issued ---------------------------------------------------------------------
     def _stream(self):
@@ -219,6 +263,16 @@ class BucketedExchange:
 
         ops._GRAD_READY[0] = None
         self._armed = False
+        if self.expected is not None and self._count != self.expected:
+            # (eager steps, warm-up passes and the capture pass alike: nothing has been launched on the communication stream
+            #  for this step yet, and a capture that raises here is discarded)
+            names = {id(p): i for i, (p, _, _) in enumerate(self.opt.slot_table())}
+            diff = [(names.get(k, -1), self.expected.get(k, 0), self._count.get(k, 0))
+                    for k in set(self.expected) | set(self._count) if self.expected.get(k, 0) != self._count.get(k, 0)]
+            self.abort()
+            raise RuntimeError(f"BucketedExchange: {len(diff)} parameters reported their gradient another number of times than in "
+                               f"the calibration pass (slot, expected, seen): {sorted(diff)[:8]} - a bucket may have been released "
+                               "before its gradients were complete; call recalibrate() if the pass structure changed on purpose")
         if self.expected is None:       # calibration pass: remember how often each parameter reports and the bucket order
             self.expected = dict(self._count)
             seen, order = set(), []
@@ -239,12 +293,21 @@ class BucketedExchange:
     # ---- after the step has been launched ----------------------------------------------------------------------------
     def launch(self, grad_scale_extra=1.0):
         """Queue wait -> all-reduce -> Adam per bucket on the communication stream.  Non-blocking for the host with RCCL."""
+        if self.step_no <= self._launched_step:
+            raise RuntimeError("BucketedExchange.launch() without a newly enqueued step (begin() / note_replay() since the last "
+                               "launch): the polling wait would be queued ahead of the kernels that release it")
+        self.check_status()
+        self._launched_step = self.step_no
         self.opt.begin_step()
         scale = grad_scale_extra / self.world
         flat = self.opt.flat_grads
         for b in self.order:
             lo, hi, _ = self.buckets[b]
-            self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, self.wait_mode, self.comm.cuda_stream), "stream_wait_ge")
+            if self.wait_mode == 0:
+                self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, 0, self.comm.cuda_stream), "stream_wait_ge")
+            else:
+                self._check(self.L.so_stream_wait_ge_bounded(self.flags[b], self.step_no, self.words, self.deadline_ticks,
+                                                             self.comm.cuda_stream), "stream_wait_ge_bounded")
             with torch.cuda.stream(self.comm):
                 if self.active:
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
@@ -256,10 +319,30 @@ class BucketedExchange:
         if self._launched:
             torch.cuda.current_stream().wait_stream(self.comm)
             self._launched = False
+        self.check_status()   # host-pinned word: no synchronisation; a time-out of step k surfaces at the latest one step later
 
     def describe(self):
         sizes = [(hi - lo) * 4 / 1e6 for lo, hi, _ in self.buckets]
         return f"{len(self.buckets)} buckets of " + "/".join(f"{x:.0f}" for x in sizes) + " MB, exchange overlapped with backward"
+
+
+def _abort_exchanges_on_error(method):
+    """Any exception escaping a step engine's __call__ first releases every bounded wait its exchanges have queued (so the
+    communication streams - and peers inside the collectives behind those waits - are not left spinning), then propagates;
+    the process is expected to exit non-zero (Trainer.fit saves its interrupt checkpoint first)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *a, **kw):
+        try:
+            return method(self, *a, **kw)
+        except BaseException:
+            for ex in self._all_exchanges():
+                if ex is not None:
+                    ex.abort()
+            raise
+
+    return wrapped
 
 
 def _make_exchange(optimizer, bucketed, bucket_bytes, group=None):
@@ -421,6 +504,10 @@ class TrainStep:
         """True when the last call completed an accumulation window (an optimizer step was issued or is pending)."""
         return self._micro == 0
 
+    def _all_exchanges(self):
+        return (self.exchange,)
+
+    @_abort_exchanges_on_error
     def __call__(self, batch):
         self.flush()  # parameters of the previous step must have landed before this forward
         if self.sync_buffers:
@@ -624,6 +711,10 @@ class ChainedTrainStep:
                 self.optu.step(grad_scale=self.redu.finish())
             self._pending_u = False
 
+    def _all_exchanges(self):
+        return (self.exw, self.exu)
+
+    @_abort_exchanges_on_error
     def __call__(self, batch=None):
         """One chained step; `batch` (device tensors of the captured shapes) is copied into the static buffers, None
         re-uses the resident batch.  Results are device tensors valid after the streams are synchronised."""
@@ -716,6 +807,7 @@ class MultiOptimizerStep:
             ex = [_make_exchange(o, bucketed, bucket_bytes) for o in self.optimizers]
             self.exchanges = ex if all(e is not None for e in ex) else None
         self.stepped = False
+        self._passes = getattr(model, "n_frames_now", None)
 
     def _only(self, idx):
         for p in self._all:
@@ -728,8 +820,18 @@ class MultiOptimizerStep:
         for p in self._all:
             p.requires_grad_(id(p) not in frozen)
 
+    def _all_exchanges(self):
+        return tuple(self.exchanges or ())
+
+    @_abort_exchanges_on_error
     def __call__(self, batch, batch_idx=0):
         results = []
+        passes = getattr(self.model, "n_frames_now", None)
+        if passes != self._passes:   # progressive training changed the number of generator passes: new report counts
+            self._passes = passes
+            for ex in self._all_exchanges():
+                if ex is not None:
+                    ex.recalibrate()
         self._micro += 1
         update = self._micro % self.accumulate == 0
         for idx, opt in enumerate(self.optimizers):

@@ -1,0 +1,270 @@
+"""Generates tests/golden/full/*.npz: the oracle (oracle/*.py) evaluated at the FULL-SIZE parity cases in fp32 and fp64
+(plus the kink-shifted fp64 passes), in the build container, so that `pytest -m gpu` on the GPU box never runs a CPU
+oracle at full size (~700 s of the 1200 s GPU run was this, with 2.5x host-to-host variance).
+
+    python tests/golden/make_golden_fullsize.py            # every case (about 1.5 h on 8 cores, <= 45 GiB)
+    python tests/golden/make_golden_fullsize.py chain_bs4 c5 ...
+
+The oracle is pinned to the imported reference by tests/golden/make_golden.py / tests/test_oracle_golden.py; this script
+imports nothing from /root/reference.  Cases and their inputs: tests/fullsize_cases.py; format: tests/gradfix.py.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TESTS = os.path.dirname(HERE)
+ROOT = os.path.dirname(TESTS)
+for p in (ROOT, TESTS):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import shineon_virtual_tryon_amd  # noqa: E402,F401
+import fullsize_cases as fc  # noqa: E402
+import gradfix as gf  # noqa: E402
+import sams_helpers as sh  # noqa: E402
+from oracle import sams_oracle as so  # noqa: E402
+from oracle import shineon_oracle as oracle  # noqa: E402
+
+
+def _params(sd, trainable, dtype):
+    return {k: (v.to(dtype).clone().requires_grad_(bool(trainable(k))) if v.is_floating_point() else v.clone())
+            for k, v in sd.items()}
+
+
+def _cast(d, dtype):
+    return {k: (v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in d.items()}
+
+
+def _grads(params):
+    return {k: v.grad for k, v in params.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+
+
+def oracle_warp(sd, batch, dtype=torch.float32, bn_updates=None):
+    params = _params(sd, lambda k: "running" not in k and "num_batches" not in k, dtype)
+    consts = _cast(oracle.tps_constants(256, 192, 5), dtype)
+    ref = oracle.warp_losses(params, _cast(batch, dtype), fc.WHP, consts, bn_updates=bn_updates)
+    ref["loss/G"].backward()
+    return params, ref
+
+
+def oracle_unet(sd, batch, hp, dtype=torch.float32):
+    params = _params(sd, lambda k: k.startswith("unet."), dtype)
+    ref = oracle.unet_mask_losses(params, _cast(batch, dtype), hp)
+    ref["loss/G"].backward()
+    return params, ref
+
+
+def kink_spread(run64, exact):
+    spread = {}
+    for sign in (1.0, -1.0):
+        with sh.kink_shift(sign * 1e-5):
+            shifted = run64()
+        for k, v in shifted.items():
+            if k in exact:
+                spread[k] = max(spread.get(k, 0.0), float((v - exact[k]).abs().max()))
+    return spread
+
+
+def gen_warp(bs, out=None, prefix=""):
+    out = {} if out is None else out
+    batch = fc.smooth_batch(bs)
+    _, sd = fc.build_warp()
+    bn = {}
+    p32, r32 = oracle_warp(sd, batch, bn_updates=bn)
+    p64, r64 = oracle_warp(sd, batch, torch.float64)
+    g32, g64 = _grads(p32), _grads(p64)
+    kink = kink_spread(lambda: _grads(oracle_warp(sd, batch, torch.float64)[0]), g64)
+    out[prefix + "digest:weights"] = gf.input_digest(sd)
+    out[prefix + "digest:batch"] = gf.input_digest(batch)
+    out[prefix + "theta32"] = r32["theta"].detach().numpy()
+    out[prefix + "theta64"] = r64["theta"].detach().numpy()
+    gf.pack_output(out, prefix + "grid", r32["grid"].permute(0, 3, 1, 2), r64["grid"].permute(0, 3, 1, 2))
+    gf.pack_output(out, prefix + "warped_cloth", r32["warped_cloth"], r64["warped_cloth"])
+    out[prefix + "handoff_f16"] = r32["warped_cloth"].detach().to(torch.float16).numpy()
+    out[prefix + "loss32"] = np.float64(float(r32["loss/G"]))
+    out[prefix + "loss64"] = np.float64(float(r64["loss/G"]))
+    for k, v in bn.items():
+        out[prefix + "bn:" + k] = v.detach().numpy()
+    gf.pack_grads(out, prefix + "grad:", g32, g64, kink)
+    return out, r32
+
+
+def gen_unet(batch, sd, hp, out=None, prefix="", kinks=True):
+    out = {} if out is None else out
+    p32, r32 = oracle_unet(sd, batch, hp)
+    p64, r64 = oracle_unet(sd, batch, hp, torch.float64)
+    g32, g64 = _grads(p32), _grads(p64)
+    # GELU U-Net: the only kinks are the VGG's ReLUs / max-pools (frozen weights; they shape dL/dp_tryon) and L1's sign
+    kink = kink_spread(lambda: _grads(oracle_unet(sd, batch, hp, torch.float64)[0]), g64) if kinks else None
+    out[prefix + "digest:weights"] = gf.input_digest(sd)
+    out[prefix + "digest:batch"] = gf.input_digest(batch)
+    for name in ("p_rendereds", "tryon_masks", "p_tryons", "flow_masks"):
+        if r32[name] is not None:
+            gf.pack_output(out, prefix + name, r32[name], r64[name])
+    for k in fc.UNET_LOG_KEYS:
+        out[prefix + "log32:" + k] = np.float64(float(r32[k]))
+        out[prefix + "log64:" + k] = np.float64(float(r64[k]))
+    gf.pack_grads(out, prefix + "grad:", g32, g64, kink)
+    return out
+
+
+def _chain(bs):
+    out, r32 = gen_warp(bs, prefix="warp:")
+    batch = dict(fc.smooth_batch(bs))
+    batch["cloth"] = fc.handoff_cloth(r32["warped_cloth"])
+    _, usd = fc.build_unet()
+    return gen_unet(batch, usd, fc.UHP, out, prefix="tryon:")
+
+
+def case_chain_bs4():
+    return _chain(4)
+
+
+def case_chain_bs8():
+    return _chain(8)
+
+
+def case_c5():
+    _, sd = fc.build_c5()
+    batch = fc.flatten_frames(fc.smooth_batch(1, n_frames=5))
+    return gen_unet(batch, sd, fc.C5HP)
+
+
+# ---- SAMS --------------------------------------------------------------------------------------------
+def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True):
+    ref32, frames32, sd32 = sh.oracle_three_steps(sd, hp, batch)
+    ref64, frames64, sd64 = sh.oracle_three_steps(sd, hp, batch, torch.float64)
+    kinks = sh.kink_spread(sd, hp, batch, ref64) if fp64_kinks else [None] * 3
+    out["digest:weights"] = gf.input_digest(sd)
+    out["digest:batch"] = gf.input_digest(batch)
+    for idx in range(3):
+        for k in ref32[idx][0]:
+            out[f"log32:{idx}:{k}"] = np.float64(ref32[idx][0][k])
+            out[f"log64:{idx}:{k}"] = np.float64(ref64[idx][0][k])
+        gf.pack_grads(out, f"grad{idx}:", ref32[idx][1], ref64[idx][1], kinks[idx])
+    f32 = frames32.reshape(frames32.shape[0], -1, *frames32.shape[-2:])
+    f64 = frames64.reshape(frames64.shape[0], -1, *frames64.shape[-2:])
+    gf.pack_output(out, "frames", f32, f64, stride=3 if f32.shape[-1] > 64 else 1)
+    out["frames:max64"] = np.float64(frames64.abs().max().item())
+    # buffers after the three steps (power-iteration vectors, running statistics, counters)
+    names, vals = [], []
+    for k, v in sd64.items():
+        if k.startswith("criterion_VGG"):
+            continue
+        if k.endswith(("weight_u", "weight_v", "running_mean", "running_var")):
+            out["buf:" + k] = v.detach().double().numpy()
+        if k.endswith("num_batches_tracked"):
+            names.append(k)
+            vals.append(int(sd32[k]))
+    out["nbt:names"] = np.array(names) if names else np.array([], dtype="<U1")
+    out["nbt:values"] = np.array(vals, np.int64)
+    return out
+
+
+def _case_sams_small(tag):
+    _, sd, hp, batch = fc.sams_small_case(tag)
+    out = _sams_three_steps(sd, hp, batch, {})
+    if tag == "base":
+        _sams_two_iterations(sd, hp, batch, out)
+    return out
+
+
+def _sams_two_iterations(sd, hp, batch, out):
+    """Two full iterations (three Adam optimizers, Lightning's order) of the fp64 oracle: every logged scalar of both
+    iterations and the total update of every parameter (tests/test_sams_gpu.py::test_sams_two_full_iterations...)."""
+    osd = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    obatch = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    groups = so.optimizer_groups(osd)
+    model = so.SamsOracle(osd, hp)
+    opts = []
+    for net, lr in zip(sh.STEP_NETS, (hp.lr, hp.lr_D, hp.lr_D)):
+        for k in groups[net]:
+            osd[k].requires_grad_(True)
+        opts.append(torch.optim.Adam([osd[k] for k in groups[net]], lr))
+    for it in range(2):
+        for idx, net in enumerate(sh.STEP_NETS):
+            for k, v in osd.items():
+                if v.is_floating_point():
+                    v.requires_grad_(k in groups[net])
+            fn = (model.generator_step, model.multiscale_discriminator_step, model.temporal_discriminator_step)[idx]
+            loss, logs = fn(obatch)
+            opts[idx].zero_grad()
+            loss.sum().backward()
+            opts[idx].step()
+            for k, v in logs.items():
+                out[f"adam:log:{it}:{idx}:{k}"] = np.float64(float(v.detach().sum()))
+    for net in sh.STEP_NETS:
+        for k in groups[net]:
+            # in units of 1e-4 (the generator's learning rate) as fp16: Adam's first steps move every element by ~lr, and the
+            # test compares direction (cosine) and length of the whole tensor's update, not elements
+            out["adam:update_e4_f16:" + k] = ((osd[k].detach() - sd[k].double()) * 1e4).to(torch.float16).numpy()
+
+
+def case_sams_base():
+    return _case_sams_small("base")
+
+
+def case_sams_attn_gelu():
+    return _case_sams_small("attn_gelu")
+
+
+def case_sams_progressive():
+    return _case_sams_small("progressive")
+
+
+def case_sams_full_three_steps():
+    hp, _, sd, batch = fc.sams_full_three_steps_case()
+    return _sams_three_steps(sd, hp, batch, {})
+
+
+def case_sams_full_generator_bs4():
+    hp, _, sd, prev_frames, prev_maps, maps, gout = fc.sams_full_generator_case()
+
+    def run(dtype):
+        osd = {k: (v.to(dtype).clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in osd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "weight_u", "weight_v")):
+                v.requires_grad_(True)
+        o = so.generator_forward(osd, prev_frames.to(dtype), prev_maps.to(dtype), {k: v.to(dtype) for k, v in maps.items()}, hp, True)
+        o.backward(gout.to(dtype))
+        return o.detach(), {k[len("generator."):]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}
+
+    o32, g32 = run(torch.float32)
+    o64, g64 = run(torch.float64)
+    spread = {}
+    for sign in (1.0, -1.0):  # as the r03 test: the bracket from two more FP32 passes at this size
+        with sh.kink_shift(sign * 1e-5):
+            _, g = run(torch.float32)
+        for k, v in g.items():
+            spread[k] = max(spread.get(k, 0.0), (v - g32[k]).abs().max().item())
+    out = {"digest:weights": gf.input_digest(sd),
+           "digest:inputs": gf.input_digest({"pf": prev_frames, "pm": prev_maps, "gout": gout, **maps})}
+    gf.pack_output(out, "out", o32, o64)
+    out["out:max64"] = np.float64(o64.abs().max().item())
+    gf.pack_grads(out, "grad:", g32, g64, spread)
+    return out
+
+
+CASES = {
+    "chain_bs4": case_chain_bs4, "chain_bs8": case_chain_bs8,
+    "c5": case_c5, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
+    "sams_progressive": case_sams_progressive, "sams_full_generator_bs4": case_sams_full_generator_bs4,
+    "sams_full_three_steps": case_sams_full_three_steps,
+}
+
+
+def main(argv):
+    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    for name in (argv or list(CASES)):
+        t0 = time.time()
+        out = CASES[name]()
+        path = gf.save(name, out)
+        print(f"{name}: {os.path.getsize(path) / 2 ** 20:.2f} MiB, {time.time() - t0:.0f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -14,10 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _spawn_pair(cmd, env, timeout=420):
-    """Start the two ranks as fresh child processes and wait.  Returns [(returncode, output)] or None when the pair did not
-    finish in time (rendezvous trouble on the box: the ranks are killed so that nothing is left on the GPU)."""
-    env = dict(env, GLOO_SOCKET_IFNAME=env.get("GLOO_SOCKET_IFNAME", "lo"), SHINEON_DIST_TIMEOUT_S="180")
+CHILD_TIMEOUT_S = 180   # every child of this file: a hang is a FAILURE within three minutes (never a skip, never a retry)
+
+
+def _spawn_pair(cmd, env, timeout=CHILD_TIMEOUT_S):
+    """Start the two ranks as fresh child processes and wait.  Returns [(returncode, output)]; a pair that does not finish in
+    time is killed (nothing is left on the GPU) and the test FAILS with what the ranks printed so far."""
+    env = dict(env, GLOO_SOCKET_IFNAME=env.get("GLOO_SOCKET_IFNAME", "lo"), SHINEON_DIST_TIMEOUT_S="120")
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True, start_new_session=True) for r in range(2)]
     outs = []
@@ -27,9 +30,8 @@ def _spawn_pair(cmd, env, timeout=420):
     except subprocess.TimeoutExpired:
         for p in procs:
             p.kill()
-        for p in procs:
-            p.communicate()
-        return None
+        tails = [p.communicate()[0] for p in procs]
+        pytest.fail(f"the two ranks did not finish within {timeout} s (killed):\n" + "\n--- other rank ---\n".join((t or "")[-2000:] for t in tails))
     return [(p.returncode, o) for p, o in zip(procs, outs)]
 
 
@@ -44,8 +46,6 @@ def _free_port():
 def _run_children(env):
     child = os.path.join(ROOT, "tests", "_dp_gpu_child.py")
     res = _spawn_pair([sys.executable, child, ROOT], dict(env, MASTER_PORT=_free_port()))
-    if res is None:
-        pytest.skip("the two ranks did not rendezvous / finish in time on this box (ranks killed)")
     for r, (rc, o) in enumerate(res):
         assert rc == 0 and f"DP_ALL_OK {r}" in o, o[-4000:]
 
@@ -77,8 +77,6 @@ def test_bench_multi_rank_code_path_two_ranks_on_one_gpu(extra, tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
            "--no-hbm-table"] + extra
     res = _spawn_pair(cmd, env)
-    if res is None:
-        pytest.skip("the two ranks did not rendezvous / finish in time on this box (ranks killed)")
     for r, (rc, o) in enumerate(res):
         assert rc == 0, f"rank {r}:\n{o[-3000:]}"
     line = json.loads([ln for ln in res[0][1].splitlines() if ln.startswith("{")][-1])
@@ -93,16 +91,20 @@ def test_single_rank_rccl_group_runs_the_exchange_path():
     trainer.TrainStep issued for real - bucketed all-reduce on the communication stream behind the in-graph signal nodes,
     Adam per bucket - must reproduce the steps without a process group bit for bit (tests/_rccl_single_rank_child.py)."""
     child = os.path.join(ROOT, "tests", "_rccl_single_rank_child.py")
-    outs = []
-    for attempt in range(2):   # one retry for the intermittent watchdog exception described below
-        p = subprocess.run([sys.executable, child, ROOT], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True, timeout=600, start_new_session=True)
-        outs.append(p.stdout)
-        if p.returncode == 0:
-            break
-    if p.returncode != 0 and all("ProcessGroupNCCL.cpp" in o and "AssertionError" not in o for o in outs):
-        pytest.skip("ProcessGroupNCCL's watchdog thread raised in both attempts (one-rank RCCL group on this box): " + p.stdout[-600:])
-    assert p.returncode == 0 and "RCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-4000:]
+    p = _run_one([sys.executable, child, ROOT], dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SHINEON_DIST_TIMEOUT_S="120"))
+    assert p.returncode == 0 and "RCCL_SINGLE_RANK_OK" in p.stdout, p.stdout[-4000:] + "\n" + p.stderr[-2000:]
+
+
+def _run_one(cmd, env):
+    """One child, one attempt: any crash - ProcessGroupNCCL's watchdog included - and any hang (killed after CHILD_TIMEOUT_S,
+    below the process group's own time-out so that the kill is not pre-empted by a watchdog message) fails the test."""
+    try:
+        return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=CHILD_TIMEOUT_S,
+                              start_new_session=True)
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = (e.stderr or b"").decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        pytest.fail(f"{' '.join(cmd[-6:])} did not finish within {CHILD_TIMEOUT_S} s (killed):\n{out[-1500:]}\n{err[-2500:]}")
 
 
 @pytest.mark.parametrize("extra,bucketed", [([], None), (["--config", "c3"], None), ([], "0")])
@@ -115,18 +117,9 @@ def test_bench_over_a_single_rank_rccl_group(extra, bucketed):
     env = dict(os.environ, SHINEON_SINGLE_RANK_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if bucketed is not None:
         env["SHINEON_BUCKETED"] = bucketed   # c4: whole-slab exchange after each graph instead of the per-model buckets
-    p = None
-    for attempt in range(2):
-        # One retry, kept as a belt: before the captures became thread-local (graphs.CAPTURE_MODE) about one start in six died
-        # because ProcessGroupNCCL's watchdog thread queried an event while this thread was capturing; the first attempt's
-        # output is kept in the failure message.
-        first = p
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, start_new_session=True)
-        if p.returncode == 0:
-            break
-    if p.returncode != 0 and first is not None and all("ProcessGroupNCCL.cpp" in q.stderr for q in (first, p)):
-        pytest.skip("ProcessGroupNCCL's watchdog thread raised in both attempts (one-rank RCCL group on this box): " + p.stderr[-600:])
-    assert p.returncode == 0, (first.stderr[-1500:] if first is not None else "") + "\n--- retry ---\n" + p.stderr[-3000:]
+    env["SHINEON_DIST_TIMEOUT_S"] = "120"
+    p = _run_one(cmd, env)
+    assert p.returncode == 0, p.stderr[-4000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["config"]["exchange"] and line["config"]["exchange_exposed_ms"] is not None, line["config"]
