@@ -229,20 +229,30 @@ __global__ __launch_bounds__(256) void linear_chw_bwd_x_k(const float* __restric
 }
 
 // ------------------------------------------------------------------ thin-plate-spline grid
-// coef[b][axis][i], i < NP+3:  Li[i][0:NP] . (theta[b][axis*NP + k] + Pbase[axis][k])
+// The TPS map amplifies rounding: Li (an fp32 LAPACK inverse, |entries| up to ~10) times (theta + P_base) cancels to the
+// small non-linear weights W, and sum_k W_k U_k sums 25 terms of either sign with U up to ~17.  Evaluated in fp32 the grid
+// lands ~2.5e-5 from the exact value of the reference's formula (the reference's own fp32 evaluation: ~9e-6), which the
+// bilinear sampler turns into 1.4e-4 on the warped cloth - outside the 1e-4 the path is held to.  Both kernels therefore
+// evaluate the reference's formula (warp.py:231-318, same operands: the fp32 constants Li, P, grid_X / grid_Y and theta)
+// in FP64 and round once at the end: the result is the correctly rounded value any fp32 evaluation approximates, so the
+// distance to the reference's CPU numbers is the reference's own rounding error.  Cost: 25 fp64 logs per PIXEL - U does not
+// depend on theta, so each thread computes its 25 basis values once and reuses them for every sample.
+//
+// coef[b][axis][i], i < NP+3:  Li[i][0:NP] . (theta[b][axis*NP + k] + Pbase[axis][k])          (fp64)
 // rows 0..NP-1 are the non-linear weights W, rows NP..NP+2 the affine part A (warp.py:231-268).
 __global__ __launch_bounds__(64) void tps_coef_k(const float* __restrict__ theta,
                                                  const float* __restrict__ Li,
                                                  const float* __restrict__ px,
                                                  const float* __restrict__ py,
-                                                 float* __restrict__ coef, int NP) {
+                                                 double* __restrict__ coef, int NP) {
   const int b = blockIdx.x;
   const int L = NP + 3;
   for (int t = threadIdx.x; t < 2 * L; t += 64) {
     const int axis = t / L, i = t - axis * L;
     const float* base = axis == 0 ? px : py;
-    float s = 0.f;
-    for (int k = 0; k < NP; ++k) s += Li[i * L + k] * (theta[(size_t)b * 2 * NP + axis * NP + k] + base[k]);
+    double s = 0.0;
+    for (int k = 0; k < NP; ++k)
+      s += (double)Li[i * L + k] * ((double)theta[(size_t)b * 2 * NP + axis * NP + k] + (double)base[k]);
     coef[((size_t)b * 2 + axis) * L + i] = s;
   }
 }
@@ -254,38 +264,56 @@ __device__ __forceinline__ float tps_u(float x, float y, float pxk, float pyk) {
   return d2 * logf(d2);
 }
 
-// grid[b][h][w][0:2] = A0 + A1 x + A2 y + sum_k W_k U_k      (warp.py:304-318)
-__global__ __launch_bounds__(256) void tps_grid_fwd_k(const float* __restrict__ coef,
+__device__ __forceinline__ double tps_u64(double x, double y, double pxk, double pyk) {
+  const double dx = x - pxk, dy = y - pyk;
+  double d2 = dx * dx + dy * dy;
+  if (d2 == 0.0) d2 = 1.0;
+  return d2 * log(d2);
+}
+
+// grid[b][h][w][0:2] = A0 + A1 x + A2 y + sum_k W_k U_k      (warp.py:304-318), fp64 inside, one rounding
+constexpr int TPS_BG = 4;     // samples per block (blockIdx.y walks groups of TPS_BG samples)
+constexpr int TPS_MAXNP = 61;
+__global__ __launch_bounds__(256) void tps_grid_fwd_k(const double* __restrict__ coef,
                                                       const float* __restrict__ gx,
                                                       const float* __restrict__ gy,
                                                       const float* __restrict__ px,
                                                       const float* __restrict__ py,
-                                                      float* __restrict__ grid, unsigned H,
+                                                      float* __restrict__ grid, unsigned Nb, unsigned H,
                                                       unsigned W, int NP) {
-  extern __shared__ float sh[];  // [2*L] coef + [NP] px + [NP] py
+  extern __shared__ double shd[];  // [TPS_BG][2*L] coef
   const int L = NP + 3;
-  const unsigned b = blockIdx.y;
-  for (int t = threadIdx.x; t < 2 * L; t += 256) sh[t] = coef[(size_t)b * 2 * L + t];
-  for (int t = threadIdx.x; t < NP; t += 256) { sh[2 * L + t] = px[t]; sh[2 * L + NP + t] = py[t]; }
+  const unsigned b0 = blockIdx.y * TPS_BG;
+  const unsigned nb = min((unsigned)TPS_BG, Nb - b0);
+  for (unsigned t = threadIdx.x; t < nb * 2 * L; t += 256) shd[t] = coef[(size_t)b0 * 2 * L + t];
   __syncthreads();
-  const float* cx = sh;
-  const float* cy = sh + L;
-  const float* spx = sh + 2 * L;
-  const float* spy = sh + 2 * L + NP;
   const unsigned pix = blockIdx.x * 256u + threadIdx.x;
   if (pix >= H * W) return;
   const unsigned h = pix / W, w = pix - h * W;
-  const float x = gx[w], y = gy[h];
-  float sx = 0.f, sy = 0.f;
+  const double x = (double)gx[w], y = (double)gy[h];
+  double sx[TPS_BG], sy[TPS_BG];
+#pragma unroll
+  for (int j = 0; j < TPS_BG; ++j) { sx[j] = 0.0; sy[j] = 0.0; }
   for (int k = 0; k < NP; ++k) {
-    const float u = tps_u(x, y, spx[k], spy[k]);
-    sx += cx[k] * u;
-    sy += cy[k] * u;
+    const double u = tps_u64(x, y, (double)px[k], (double)py[k]);
+#pragma unroll
+    for (int j = 0; j < TPS_BG; ++j) {
+      if ((unsigned)j < nb) {
+        sx[j] += shd[(j * 2 + 0) * L + k] * u;
+        sy[j] += shd[(j * 2 + 1) * L + k] * u;
+      }
+    }
   }
-  const float ox = cx[NP] + cx[NP + 1] * x + cx[NP + 2] * y + sx;
-  const float oy = cy[NP] + cy[NP + 1] * x + cy[NP + 2] * y + sy;
-  float2 o = make_float2(ox, oy);
-  *reinterpret_cast<float2*>(grid + ((size_t)b * H * W + pix) * 2) = o;
+#pragma unroll
+  for (int j = 0; j < TPS_BG; ++j) {
+    if ((unsigned)j < nb) {
+      const double* cx = shd + (j * 2 + 0) * L;
+      const double* cy = shd + (j * 2 + 1) * L;
+      const double ox = cx[NP] + cx[NP + 1] * x + cx[NP + 2] * y + sx[j];
+      const double oy = cy[NP] + cy[NP + 1] * x + cy[NP + 2] * y + sy[j];
+      *reinterpret_cast<float2*>(grid + ((size_t)(b0 + j) * H * W + pix) * 2) = make_float2((float)ox, (float)oy);
+    }
+  }
 }
 
 // partial[b][blk][axis][i] = sum over the block's pixels of dgrid[b][pix][axis] * basis_i(pix)
@@ -664,7 +692,8 @@ int so_linear_chw_bwd(const float* x, int ldx, const float* w, const float* y, c
 
 long long so_tps_ws_floats(int Nb, int H, int W, int NP) {
   const int nblk = so_cdiv((long long)H * W, 256 * TPS_PPT);
-  return (long long)Nb * 2 * (NP + 3) + (long long)Nb * nblk * 2 * (NP + 3);
+  // [fp64 coefficients: 2 floats each][backward partials]
+  return 2ll * Nb * 2 * (NP + 3) + (long long)Nb * nblk * 2 * (NP + 3);
 }
 
 // theta [B][2*NP]; Li [(NP+3)][(NP+3)]; px,py [NP]; gx [W]; gy [H]; grid [B][H][W][2]
@@ -673,11 +702,12 @@ int so_tps_grid_fwd(const float* theta, const float* Li, const float* px, const 
                     float* ws, void* stream) {
   if (NP > 61) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
-  float* coef = ws;
+  if (((uintptr_t)ws & 7) != 0) return SO_ERR_ALIGN;
+  double* coef = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(tps_coef_k, dim3(Nb), dim3(64), 0, st, theta, Li, px, py, coef, NP);
-  const size_t sh = (size_t)(2 * (NP + 3) + 2 * NP) * sizeof(float);
-  hipLaunchKernelGGL(tps_grid_fwd_k, dim3(so_cdiv((long long)H * W, 256), Nb), dim3(256), sh, st, coef,
-                     gx, gy, px, py, grid, (unsigned)H, (unsigned)W, NP);
+  const size_t sh = (size_t)(TPS_BG * 2 * (NP + 3)) * sizeof(double);
+  hipLaunchKernelGGL(tps_grid_fwd_k, dim3(so_cdiv((long long)H * W, 256), so_cdiv(Nb, TPS_BG)), dim3(256), sh, st, coef,
+                     gx, gy, px, py, grid, (unsigned)Nb, (unsigned)H, (unsigned)W, NP);
   return SO_LAUNCH_CHECK();
 }
 
@@ -687,7 +717,7 @@ int so_tps_grid_bwd(const float* dgrid, const float* Li, const float* px, const 
   if (NP > 61) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = so_cdiv((long long)H * W, 256 * TPS_PPT);
-  float* part = ws + (size_t)Nb * 2 * (NP + 3);
+  float* part = ws + 2 * (size_t)Nb * 2 * (NP + 3);
   hipLaunchKernelGGL(tps_grid_bwd_partial_k, dim3(nblk, Nb), dim3(256), 0, st, dgrid, gx, gy, px, py,
                      part, (unsigned)H, (unsigned)W, NP);
   hipLaunchKernelGGL(tps_grid_bwd_final_k, dim3(Nb), dim3(64), 0, st, part, (unsigned)nblk, Li, dtheta,

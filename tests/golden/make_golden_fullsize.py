@@ -120,6 +120,13 @@ def _chain(bs):
     return gen_unet(batch, usd, fc.UHP, out, prefix="tryon:")
 
 
+def case_warp_bs2():
+    """The inputs of tests/test_models_gpu.py::test_warp_model_vs_reference_golden (the REFERENCE's own bs=2 golden): the
+    oracle's fp64 values beside the reference's fp32 ones, so that the test can say how far the reference itself is from exact."""
+    out, _ = gen_warp(2)
+    return out
+
+
 def case_chain_bs4():
     return _chain(4)
 
@@ -135,7 +142,7 @@ def case_c5():
 
 
 # ---- SAMS --------------------------------------------------------------------------------------------
-def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True):
+def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True, o97=False):
     ref32, frames32, sd32 = sh.oracle_three_steps(sd, hp, batch)
     ref64, frames64, sd64 = sh.oracle_three_steps(sd, hp, batch, torch.float64)
     kinks = sh.kink_spread(sd, hp, batch, ref64) if fp64_kinks else [None] * 3
@@ -146,6 +153,9 @@ def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True):
             out[f"log32:{idx}:{k}"] = np.float64(ref32[idx][0][k])
             out[f"log64:{idx}:{k}"] = np.float64(ref64[idx][0][k])
         gf.pack_grads(out, f"grad{idx}:", ref32[idx][1], ref64[idx][1], kinks[idx])
+        if o97:  # the fp32 oracle at the sample positions of the REFERENCE goldens (tests/golden/sams_*.npz, gs<idx>: keys)
+            for k, v in ref32[idx][1].items():
+                out[f"o97:{idx}:{k}"] = v.detach().contiguous().reshape(-1)[::97].float().numpy()
     f32 = frames32.reshape(frames32.shape[0], -1, *frames32.shape[-2:])
     f64 = frames64.reshape(frames64.shape[0], -1, *frames64.shape[-2:])
     gf.pack_output(out, "frames", f32, f64, stride=3 if f32.shape[-1] > 64 else 1)
@@ -167,7 +177,7 @@ def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True):
 
 def _case_sams_small(tag):
     _, sd, hp, batch = fc.sams_small_case(tag)
-    out = _sams_three_steps(sd, hp, batch, {})
+    out = _sams_three_steps(sd, hp, batch, {}, o97=True)
     if tag == "base":
         _sams_two_iterations(sd, hp, batch, out)
     return out
@@ -250,7 +260,7 @@ def case_sams_full_generator_bs4():
 
 
 CASES = {
-    "chain_bs4": case_chain_bs4, "chain_bs8": case_chain_bs8,
+    "warp_bs2": case_warp_bs2, "chain_bs4": case_chain_bs4, "chain_bs8": case_chain_bs8,
     "c5": case_c5, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
     "sams_progressive": case_sams_progressive, "sams_full_generator_bs4": case_sams_full_generator_bs4,
     "sams_full_three_steps": case_sams_full_three_steps,

@@ -36,11 +36,23 @@ def test_warp_model_vs_reference_golden(cuda):
     with torch.no_grad():
         grid, theta = model2(person, batch["cloth"])
     assert_close(theta, g["theta"], atol=2e-5, what="theta")
-    assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=5e-5, what="grid")
-    # warped cloth: bilinear sampling amplifies the <= 5e-5 grid difference by the image slope (up to ~2.5 per unit of
-    # normalised coordinate for the band-limited fixture): 1.2e-4 at 3 of the 4608 golden samples.  The sampling itself is
-    # exact: ATen's grid_sample on OUR grid reproduces our output to 1e-5 (and the integer taps are bit-exact).
-    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=2e-4, what="warped cloth")
+    # The TPS map is evaluated in fp64 and rounded once (exact on a given theta, tests/test_ops_gpu.py::test_tps_grid); the grid
+    # difference to the reference is its ~3.7x amplification of the theta difference (9.4e-6 measured here: two fp32
+    # evaluations of 16 layers, each ~5e-6 from the exact value): 2.0e-5 measured.
+    assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=3e-5, what="grid")
+    # warped cloth: bilinear sampling amplifies the grid difference by the image slope (~5 per unit of normalised coordinate
+    # for the band-limited fixture): 1.2e-4 at 3 of the 4608 REFERENCE samples.  The north-star 1e-4 is therefore stated the
+    # way tests/test_parity_bs4_gpu.py states it - against the reference's value OR the exact (fp64) value of the same graph,
+    # the oracle's (tests/golden/full/warp_bs2.npz): every element within 1e-4 of the fp32 value or within 1e-4 + the fp32
+    # reference's own distance from exact, and never more than twice as far from exact as the reference is.  The sampling
+    # itself is exact: ATen's grid_sample on OUR grid reproduces our output to 1e-5 (and the integer taps are bit-exact).
+    assert_close(strided(model.warped_cloth), g["warped_cloth_s8"], atol=1.5e-4, what="warped cloth vs the reference's samples")
+    import gradfix as gf
+
+    fix = gf.load("warp_bs2")
+    gf.check_digest(fix, "digest:weights", golden_state(g))
+    gf.check_output(fix, "grid", grid.permute(0, 3, 1, 2), 3e-5, "warp bs=2", mode="either")
+    gf.check_output(fix, "warped_cloth", model.warped_cloth, 1e-4, "warp bs=2", mode="either")
     resampled = oracle.grid_sample(batch["cloth"].cpu(), grid.cpu(), "border")  # model2 == model: the same grid
     assert_close(model.warped_cloth, resampled, atol=1e-5, what="grid_sample(cloth, OUR grid) vs ATen on the same grid")
     assert abs(res.minimize.item() - float(g["loss"])) < 2e-5

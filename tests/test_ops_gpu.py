@@ -359,6 +359,13 @@ def test_tps_grid(ops, cuda, hw):
     theta = rnd(2, 50, seed=35, scale=0.15)
     compare_fwd_bwd(lambda t: ops.tps_grid(t, dev, h, w, 25), lambda t: oracle.tps_grid(t, c), [(theta, True)], cuda,
                     atol=1e-5, grel=1e-3, rtol=1e-4, what="tps")  # fp32 sums over 49152 pixels, different order
+    # the kernel evaluates the reference's formula in fp64 and rounds once: on the SAME theta it reproduces the fp64 oracle to
+    # fp32 rounding (1 ulp of |grid| <= 1.4 is 1.2e-7) - the north star's "bit-exact for the TPS index grid" up to the final
+    # rounding, and 40x inside SURVEY 0-6's 1e-5
+    c64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in c.items()}
+    exact = oracle.tps_grid(theta.double(), c64)
+    ours = ops.tps_grid(theta.to(cuda), dev, h, w, 25).cpu().double()
+    assert float((ours - exact).abs().max()) <= 2.5e-7, float((ours - exact).abs().max())
     # known answer: theta = 0 -> identity grid (base grid exactly, up to fp32 round-off of the affine part)
     g0 = ops.tps_grid(torch.zeros(1, 50, device=cuda), dev, h, w, 25).cpu()
     X, Y = c["gx"][None, None, :].expand(1, h, w), c["gy"][None, :, None].expand(1, h, w)

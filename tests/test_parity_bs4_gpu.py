@@ -36,13 +36,20 @@ def _check_warp(fix, model, twin_out, batch_cpu, loss, what, pfx="warp:"):
     if twin_out is not None:
         grid, theta = twin_out
         assert_close(theta, fix[pfx + "theta32"], atol=1e-4, what=f"{what}: theta")
-        gf.check_output(fix, pfx + "grid", grid.permute(0, 3, 1, 2), 1e-4, what, either=False)
+        gf.check_output(fix, pfx + "grid", grid.permute(0, 3, 1, 2), 3e-5, what, mode="either")
         # grid_sample given OUR grid, evaluated by ATen on the CPU (milliseconds), agrees with our kernel to 1e-5 (and the
         # integer taps are bit-exact, tests/test_ops_gpu.py): what remains between `warped_cloth` and the oracle's
         # end-to-end value is the sensitivity of bilinear sampling to a ~1e-5 grid difference.
         resampled = oracle.grid_sample(batch_cpu["cloth"], grid.detach().cpu(), "border")
         assert_close(model.warped_cloth, resampled, atol=1e-5, what=f"{what}: grid_sample(cloth, OUR grid) vs ATen on the same grid")
-    gf.check_output(fix, pfx + "warped_cloth", model.warped_cloth, 1e-4, what, either=False)
+    # The TPS map itself is evaluated in fp64 and rounded once (csrc/gmm.hip; tests/test_ops_gpu.py::test_tps_grid pins it
+    # to 2.5e-7 of the fp64 oracle on the same theta).  What is left between two fp32 evaluations of the MODEL is theta: ours
+    # and the reference's CPU value each sit ~5e-6 from the exact theta (tools/probes/warp_precision.py: 4.8e-6 / 4.9e-6 at
+    # bs=4), the TPS map amplifies a theta difference ~3.7x into the grid and the bilinear sampler ~5x more (image slope x
+    # 96 px per unit) into the cloth: the fp32 reference ITSELF is 7.5e-5 from the exact warped cloth.  Rule "either": within
+    # 1e-4 of the fp32 oracle, or no further from the exact (fp64) value than 1e-4 + the reference's own distance from it -
+    # and never more than twice as far from the exact value as the reference is.
+    gf.check_output(fix, pfx + "warped_cloth", model.warped_cloth, 1e-4, what, mode="either")
     assert abs(float(loss) - float(fix[pfx + "loss32"])) <= 2e-5, (float(loss), float(fix[pfx + "loss32"]))
     routes = gf.compare_grads(_grads(model), gf.GradFixture(fix, pfx + "grad:"), what, rule="tryon")
     assert len(routes) == 62  # 2 x (6 conv + 5 BN) x (w, b) + regression (4 conv + 4 BN + linear) x (w, b)
