@@ -143,6 +143,11 @@ int so_igemm_plans_load(const char* path);
  * 2 64x128, 3 128x128, 4 128x128/8 waves, 5 64x128/8 waves, 6 the 4x4x1-MFMA kernels for four-channel convolutions,
  * 7 (group 0) the fused Winograd kernel): summed milliseconds, summed algorithmic FLOPs (2*M*N*K per launch; the fused
  * Winograd kernel: the direct convolution's), launch count.  Returns the number of launches collected and clears the list. */
+/* Split-K summation: 0 (default) - a separate reduce launch; 1 (SHINEON_SPLITK_FIXUP=1 in the environment) - the last block to
+ * arrive at an output tile sums the slabs and applies the epilogue inside the GEMM launch (library-owned arrival counters,
+ * agent-scope write-through slab traffic).  Both sum the slabs in the same fixed order: results are bit-identical; the fix-up
+ * measured 2 % slower on MI355X (private per-XCD L2s; csrc/igemm2.hip has the numbers), hence opt-in. */
+void so_igemm_fixup(int on);
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
 /* the same + out_bytes[k] (HOST array of 40 doubles; may be NULL): summed ALGORITHMIC HBM bytes of the launches under key k -
