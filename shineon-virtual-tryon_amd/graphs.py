@@ -14,7 +14,13 @@ import torch
 # (hipEventQuery) - under the default GLOBAL capture mode such a call from ANOTHER thread is "not permitted when stream is
 # capturing", invalidates the capture and kills the process (seen in about one start in six over a one-rank RCCL group; it
 # would hit every multi-GPU run the same way).  Only this thread's own calls need to be capture-safe.
-CAPTURE_MODE = "thread_local"
+#
+# thread_local also relaxes checking for the autograd worker thread (where every backward node of the captured step runs), so
+# it is used ONLY while a process group exists; a single process captures in the strict "global" mode.
+def capture_mode():
+    import torch.distributed as dist
+
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
 
 
 class GraphedTrainStep:
@@ -38,7 +44,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
             self._step()
 
     def _step(self):
@@ -139,10 +145,10 @@ class GraphedChainedStep:
         cs = torch.cuda.Stream()
         self.g_wf, self.g_wb, self.g_u = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with ops.workspace_lane(8):
-            with torch.cuda.graph(self.g_wf, stream=cs, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(self.g_wf, stream=cs, capture_error_mode=capture_mode()):
                 optw.zero_grad()
                 rw = warp.training_step(sb, 0)
-            with torch.cuda.graph(self.g_wb, stream=cs, capture_error_mode=CAPTURE_MODE):
+            with torch.cuda.graph(self.g_wb, stream=cs, capture_error_mode=capture_mode()):
                 if exw is not None:
                     exw.begin()
                 rw.minimize.backward()
@@ -155,7 +161,7 @@ class GraphedChainedStep:
         self.cloth_tryon.copy_(self.warped)
         b2 = dict(self.batch_tryon)
         b2["cloth"] = self.cloth_tryon
-        with torch.cuda.graph(self.g_u, capture_error_mode=CAPTURE_MODE):
+        with torch.cuda.graph(self.g_u, capture_error_mode=capture_mode()):
             optu.zero_grad()
             if exu is not None:
                 exu.begin()

@@ -557,17 +557,32 @@ class ChainedTrainStep:
         self.batch = sample_batch
         optw.zero_grad()
         optu.zero_grad()
-        # The try-on exchange gets a communicator (and with it a stream) of its OWN.  Collectives of one process group run in
-        # issue order: on a shared communicator the warp model's buffer broadcast of step k+1 queues behind the try-on
-        # all-reduce of step k - i.e. behind the END of the try-on graph - and the warp forward that should overlap that graph
-        # starts after it.
-        self.group_u = dist.new_group() if _collective() else None
+        # ONE communicator by default: both models' collectives are issued in the same host order on every rank and run in
+        # that order on RCCL's stream, so no rank can start them in another order than its peers.  (Two communicators whose
+        # kernels are released by device-side events start in a RANK-DEPENDENT order; when their streams share a hardware
+        # queue each rank can end up waiting inside one collective for a peer that sits inside the other - the pattern NCCL
+        # documents as deadlock-prone.  It has only ever run over the ONE-rank group here, where nothing waits for a peer.)
+        # What made one communicator slow in round 3 (+0.62 ms/step) was the warp model's per-step buffer broadcast queueing
+        # behind the try-on all-reduce, i.e. behind the end of the try-on graph; the broadcast is now LAZY (see
+        # `lazy_buffers`), which removes that collective from the step altogether.
+        # SHINEON_TWO_COMMUNICATORS=1: the try-on exchange on its own communicator / stream with the per-bucket exchange
+        # (round 3's schedule; measured 6.73 vs 6.87 ms over the one-rank group) - opt-in until it has met a real wire.
+        two = os.environ.get("SHINEON_TWO_COMMUNICATORS", "0") == "1"
+        self.group_u = dist.new_group() if (_collective() and two) else None
         self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads, group=self.group_u)
         self.exw = self.exu = None
+        if bucketed is None and os.environ.get("SHINEON_BUCKETED") is None and not two:
+            bucketed = False   # whole-slab exchange after each graph: host-ordered on the one communicator
         if schedule != "eager":
             self.exw = _make_exchange(optw, bucketed, bucket_bytes)
             self.exu = _make_exchange(optu, bucketed, bucket_bytes, group=self.group_u) if self.exw is not None else None
         self.sync_buffers = sync_buffers and _collective() and flatten_float_buffers(warp) is not None
+        # BatchNorm running statistics are not READ by a training-mode forward, so DDP's per-forward broadcast of rank 0's
+        # buffers only matters when somebody looks at them: validation, a checkpoint, the end of training.  Lazy = rank 0's
+        # statistics are broadcast in synchronize() (every consumer calls it first) instead of before every step - the
+        # values every observer sees are the ones DDP would show (rank 0's chain of updates), one collective per step less.
+        # SHINEON_BROADCAST_BUFFERS_EVERY_STEP=1 restores the literal per-step broadcast.
+        self.lazy_buffers = os.environ.get("SHINEON_BROADCAST_BUFFERS_EVERY_STEP", "0") != "1"
         self._pending_u = False
         self._gp = self._gw = self._gu = None
         self.exchange_ms = self.pipeline_gain_ms = None
@@ -686,7 +701,7 @@ class ChainedTrainStep:
     def eager_step(self, batch=None, update=True):
         batch = self.batch if batch is None else batch
         self.flush()
-        if self.sync_buffers and update:
+        if self.sync_buffers and update and not self.lazy_buffers:
             broadcast_buffers(self.warp)
         self.optw.zero_grad()
         rw = self.warp.training_step(batch, 0)
@@ -722,7 +737,7 @@ class ChainedTrainStep:
             return self.eager_step(batch)
         gp = self._gp
         if gp is not None:
-            if self.sync_buffers:
+            if self.sync_buffers and not self.lazy_buffers:
                 with gp.on_side():
                     broadcast_buffers(self.warp)
             if self.exw is not None:
@@ -744,7 +759,7 @@ class ChainedTrainStep:
                 self.redu.start()
             self._pending_u = True
             return gp.result_warp, gp.result_tryon
-        if self.sync_buffers:
+        if self.sync_buffers and not self.lazy_buffers:
             broadcast_buffers(self.warp)
         if self.exw is not None:
             self.exw.finish()
@@ -767,11 +782,15 @@ class ChainedTrainStep:
         return rw, ru
 
     def synchronize(self):
+        """Everything in flight lands; with lazy buffer broadcast this is also where rank 0's BatchNorm running statistics
+        reach the other ranks (call it before validation / a checkpoint / reading the buffers)."""
         self.flush()
         if self.exw is not None:
             self.exw.finish()
         if self._gp is not None:
             self._gp.join()
+        if self.sync_buffers and self.lazy_buffers:
+            broadcast_buffers(self.warp)
         torch.cuda.synchronize()
 
 
