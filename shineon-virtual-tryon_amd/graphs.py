@@ -103,6 +103,8 @@ class GraphedChainedStep:
         from . import ops
 
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
+        if hasattr(warp, "tower_streams"):
+            warp.tower_streams = False   # the warp stage already runs beside the try-on stage: no third stream (warp_model.py)
         self.exchange_w, self.exchange_u = exchange_w, exchange_u
         exw, exu = exchange_w, exchange_u
         clone = lambda: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in sample_batch.items()}

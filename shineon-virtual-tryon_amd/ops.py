@@ -1690,3 +1690,40 @@ def vgg_target_features(y, cfg, params):
                 feats.append(out)
         cur = out
     return feats
+
+
+# ------------------------------------------------------------------------------------------------
+# scratch lanes follow an operator into its backward pass
+# ------------------------------------------------------------------------------------------------
+def _lane_aware(cls):
+    """An operator issued under `workspace_lane(b)` (a branch running concurrently on another stream) must use the same scratch
+    lane in its BACKWARD pass - autograd runs it later, outside the `with` block, on that branch's stream, concurrently with the
+    other branch's backward nodes.  forward() records the lane base in ctx, backward() re-enters it."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._so_lane_base = _LANE_BASE[0]
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        prev = _LANE_BASE[0]
+        _LANE_BASE[0] = getattr(ctx, "_so_lane_base", prev)
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            _LANE_BASE[0] = prev
+
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
+
+
+def make_functions_lane_aware(namespace):
+    for obj in list(namespace.values()):
+        if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function \
+                and not getattr(obj, "_so_lane_aware", False) and obj.__module__ == namespace.get("__name__"):
+            _lane_aware(obj)
+            obj._so_lane_aware = True
+
+
+make_functions_lane_aware(globals())

@@ -335,3 +335,8 @@ def gan_loss(x, mode, target_is_real, for_discriminator=True):
     if mode == "hinge" and not for_discriminator and not target_is_real:
         raise AssertionError("The generator's hinge loss must be aiming for real")
     return _GanLossFn.apply(x, GAN_MODES[mode], int(bool(target_is_real)), int(bool(for_discriminator)))
+
+
+from .ops import make_functions_lane_aware  # noqa: E402
+
+make_functions_lane_aware(globals())

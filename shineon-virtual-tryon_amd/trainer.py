@@ -555,6 +555,8 @@ class ChainedTrainStep:
         with or without collectives)."""
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
         self.batch = sample_batch
+        if hasattr(warp, "tower_streams"):
+            warp.tower_streams = False   # a third concurrent stream slows the chained schedules down (warp_model.py)
         optw.zero_grad()
         optu.zero_grad()
         # ONE communicator by default: both models' collectives are issued in the same host order on every rank and run in

@@ -4,6 +4,7 @@ forward: features(person), features(cloth) -> L2 norm -> correlation -> regressi
 training_step: L1(grid_sample(cloth, grid, border), im_cloth).
 """
 import argparse
+import os
 from argparse import ArgumentParser
 
 from torch import nn
@@ -16,6 +17,10 @@ from .networks.cpvton.warp import (FeatureCorrelation, FeatureExtraction, Featur
                                    TpsGridGen)
 from .pl_compat import EvalResult, TrainResult
 from .util import get_and_cat_inputs, maybe_combine_frames_and_channels
+
+
+# the two towers on two streams (see WarpModel.forward); SHINEON_TOWER_STREAMS=0 runs them one after the other
+TOWER_STREAMS = os.environ.get("SHINEON_TOWER_STREAMS", "1") != "0"
 
 
 class WarpModel(BaseModel):
@@ -39,6 +44,10 @@ class WarpModel(BaseModel):
         self.correlation = FeatureCorrelation()
         self.regression = FeatureRegression(input_nc=192, output_dim=2 * hparams.grid_size ** 2)
         self.gridGen = TpsGridGen(hparams.fine_height, hparams.fine_width, grid_size=hparams.grid_size)
+        # the cloth tower on a forked stream (forward()).  Measured on MI355X, bs=4: WarpModel alone 1610 -> 1908 frames/s; inside
+        # the chained warp -> try-on schedule (whose warp stage already shares the chip with the try-on stage on a second
+        # stream) 612 -> 521, so trainer.ChainedTrainStep switches it off for its warp model.
+        self.tower_streams = TOWER_STREAMS
 
     def batch_keys(self):
         """Tensor entries of the batch dict this model reads (training / validation / test)."""
@@ -65,10 +74,21 @@ class WarpModel(BaseModel):
     def forward(self, inputA, inputB):
         if self.training:
             self._bump_bn_counters()
-        featureA = self.extractionA(inputA)
-        featureB = self.extractionB(inputB)
-        featureA = self.l2norm(featureA, transpose_hw=True)  # the h<->w transpose of warp.py:60 is fused here
-        featureB = self.l2norm(featureB)
+        if self.tower_streams and inputA.is_cuda:
+            # The two feature-extraction towers (warp.py:9-36) are independent until the correlation and, at 16x12 .. 128x96
+            # feature maps, every one of their kernels fills a fraction of the 256 CUs: the cloth tower runs on a forked stream
+            # with its own scratch lane (eagerly and as a parallel branch of a captured graph); autograd replays the same
+            # two-stream structure in the backward pass (each node on the stream and scratch lane of its forward op).
+            fork = ops._SideStream(inputA.device)
+            with fork, ops.workspace_lane(ops._LANE_BASE[0] + 16):
+                featureB = self.l2norm(self.extractionB(inputB))
+            featureA = self.l2norm(self.extractionA(inputA), transpose_hw=True)  # the h<->w transpose of warp.py:60 is fused here
+            fork.join()
+        else:
+            featureA = self.extractionA(inputA)
+            featureB = self.extractionB(inputB)
+            featureA = self.l2norm(featureA, transpose_hw=True)  # the h<->w transpose of warp.py:60 is fused here
+            featureB = self.l2norm(featureB)
         correlation = self.correlation(featureA, featureB, a_is_transposed=True)
         theta = self.regression(correlation)
         grid = self.gridGen(theta)
