@@ -307,7 +307,17 @@ def check_routes(what, rule, routes):
     order = ROUTE_ORDER[rule]
     worse = [f"{k}: {ref['routes'][k]} -> {v}" for k, v in routes.items()
              if k in ref["routes"] and order.index(v.split("/")[0]) > order.index(ref["routes"][k])]
-    assert not worse, f"{what}: {len(worse)} tensors now need a weaker acceptance route than the committed tally: " + "; ".join(worse[:10])
+    msg = f"{what}: {len(worse)} tensors now need a weaker acceptance route than the committed tally: " + "; ".join(worse[:10])
+    if ref.get("strict", True):
+        # every layer shape of these cases has a COMMITTED igemm plan (plans/gfx950.txt): same kernels, same summation order,
+        # same bits on every box - a route change is a code change
+        assert not worse, msg
+    elif worse:
+        # SAMS cases: some of their layer shapes are measured per process (no committed plan), so the split-K order - and with
+        # it a tensor sitting on a route boundary - may differ between boxes: reported, not failed
+        import warnings
+
+        warnings.warn(msg)
 
 
 def check_scalar(ours, r32, r64, tol_abs, tol_rel, what):
