@@ -26,6 +26,20 @@ from helpers import assert_close, oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def no_layer_shape_is_measured_here(cuda):
+    """Every layer shape these tests launch has a COMMITTED igemm plan: nothing is autotuned inside them, so the kernels, the
+    split-K summation order and therefore every bit of the results are the same on every box - which is what lets
+    tests/golden/full/routes.json pin each gradient tensor's acceptance route strictly."""
+    import shineon_virtual_tryon_amd as pkg
+
+    L = pkg.lib()
+    before = L.so_igemm_plan_count()
+    yield
+    assert L.so_igemm_plan_count() == before, (f"{L.so_igemm_plan_count() - before} layer shapes without a committed plan were "
+                                                "measured during this test: regenerate plans/gfx950.txt (tools/make_plans.py)")
+
+
 def _grads(model, prefix=""):
     return {name: p.grad for name, p in model.named_parameters() if p.requires_grad and name.startswith(prefix)}
 
