@@ -8,7 +8,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
 # 1. bench lines (graph replay, CPU baseline on) + per-launch timing dump of the instrumented eager pass
-for CFG in c4 c2 c3; do
+for CFG in c4 c1 c2 c3 c5 sams; do
   SO_PROF_DUMP=$OUT/${TAG}_${CFG}_igemm_launches.csv python3 bench.py --config $CFG > $OUT/${TAG}_bench_${CFG}.json 2> $OUT/${TAG}_bench_${CFG}.log
 done
 # 2. kernel trace of the headline command
@@ -26,6 +26,15 @@ for PASS in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 300 rocprofv3 --kernel-trace --pmc $PASS -d /tmp/prof_pmc -o r -- python3 $R/tools/one_layer.py wino 4 256 192 128 256 3 1 1 > $OUT/${TAG}_pmc_sams_layer_$PASS.log 2>&1
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_wino_fused_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
+done
+# SAMS, the REAL step (bs = 1, one step) with the counters restricted to its dominant kernel (--kernel-include-regex): the
+# unfiltered passes of rounds 2 and 3 killed the process; if this one survives, traffic.json [sams] comes from the step itself
+for PASS in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_pmc
+  timeout -k 5 420 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "wino_fused_k" -d /tmp/prof_pmc -o r -- python3 $R/bench.py --config sams --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-table > $OUT/${TAG}_pmc_sams_step_$PASS.log 2>&1
+  echo "sams step pmc $PASS rc=$?" >> $OUT/${TAG}_kernel_trace_summary.txt
+  DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
+  [ -n "$DB" ] && python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_step_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
 done
 for CFG in c4 c2 c3; do
   EXTRA="--steps 3 --warmup 1 --no-graph"
@@ -45,5 +54,5 @@ for CFG in c4 c3 sams; do
   SHINEON_SINGLE_RANK_GROUP=1 timeout -k 5 600 python3 bench.py --config $CFG --no-cpu-baseline --no-hbm-table 2> $OUT/${TAG}_single_rank_rccl_${CFG}.log | grep '^{' > $OUT/${TAG}_bench_${CFG}_single_rank_rccl.json
   grep "exposed\|timed\|backend" $OUT/${TAG}_single_rank_rccl_${CFG}.log
 done
-for CFG in c4 c2 c3; do tail -1 $OUT/${TAG}_bench_${CFG}.json | cut -c1-300; done
+for CFG in c4 c1 c2 c3 c5 sams; do tail -1 $OUT/${TAG}_bench_${CFG}.json | cut -c1-300; done
 cat $OUT/${TAG}_kernel_trace_summary.txt
