@@ -586,6 +586,7 @@ class ChainedTrainStep:
         # SHINEON_BROADCAST_BUFFERS_EVERY_STEP=1 restores the literal per-step broadcast.
         self.lazy_buffers = os.environ.get("SHINEON_BROADCAST_BUFFERS_EVERY_STEP", "0") != "1"
         self._pending_u = False
+        self._u_started = False      # whole-slab mode: the try-on all-reduce of the pending step has been issued
         self._gp = self._gw = self._gu = None
         self.exchange_ms = self.pipeline_gain_ms = None
         auto = schedule == "auto" and _collective()
@@ -725,8 +726,11 @@ class ChainedTrainStep:
             if self.exu is not None:
                 self.exu.finish()
             else:
+                if not self._u_started:
+                    self.redu.start()
                 self.optu.step(grad_scale=self.redu.finish())
             self._pending_u = False
+            self._u_started = False
 
     def _all_exchanges(self):
         return (self.exw, self.exu)
@@ -745,6 +749,26 @@ class ChainedTrainStep:
             if self.exw is not None:
                 with gp.on_side():
                     self.exw.finish()   # the previous step's warp update has landed before this warp forward
+            if self.exw is None and self.exu is None:
+                # Whole-slab exchange on ONE communicator: collectives run in host issue order, so they are issued in the order
+                # they become READY on the device.  The warp stage of step k (forward, backward - neither depends on the
+                # try-on stage) runs entirely beside the try-on stage of step k-1, so its gradients W_k are ready BEFORE the
+                # try-on gradients U_{k-1}: W_k is issued first, U_{k-1} behind it.  (Issued the other way round - round 3's
+                # order - W_k queues behind a collective that cannot start before the try-on graph ends: 0.64 ms per step
+                # over the one-rank RCCL group, profiles/r04_single_rank_rccl.txt.)
+                gp.launch_warp_forward(batch)
+                gp.launch_warp_backward()
+                with gp.on_side():
+                    self.redw.start()
+                if self._pending_u and not self._u_started:
+                    self.redu.start()           # U_{k-1}: waits for the try-on graph launched by the previous call
+                    self._u_started = True
+                with gp.on_side():
+                    self.optw.step(grad_scale=self.redw.finish())
+                self.flush()                    # try-on Adam of step k-1 on the main stream
+                gp.launch_tryon(batch)
+                self._pending_u, self._u_started = True, False
+                return gp.result_warp, gp.result_tryon
             gp.launch_warp_forward(batch)
             self.flush()
             gp.launch_tryon(batch)
@@ -759,6 +783,7 @@ class ChainedTrainStep:
                     self.optw.step(grad_scale=self.redw.finish())
             if self.exu is None:
                 self.redu.start()
+                self._u_started = True
             self._pending_u = True
             return gp.result_warp, gp.result_tryon
         if self.sync_buffers and not self.lazy_buffers:
@@ -778,6 +803,7 @@ class ChainedTrainStep:
             self.exu.launch()
         else:
             self.redu.start()
+            self._u_started = True
         self._pending_u = True
         if self.exw is None:
             self.optw.step(grad_scale=self.redw.finish())
