@@ -159,6 +159,16 @@ def sams_traffic(key):
     return json.load(open(tpath)).get("sams", {}).get(key, {}).get("hbm_bytes_per_launch")
 
 
+def sams_traffic_source():
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    src = (json.load(open(tpath)).get("sams", {}).get("_sources") or [""]) if os.path.exists(tpath) else [""]
+    if "sams_step" in src[0]:
+        return ("profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on THIS step (bs = 4, one step, counters "
+                "restricted to the kernel with --kernel-include-regex), bytes per launch averaged over its launches")
+    return ("profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the kernel's most frequent layer of this step "
+            "(128 -> 256 channels, 256x192, bs = 4) in a single-layer process (tools/one_layer.py), bytes per launch")
+
+
 def sams_hbm_table(dev, batch_size):
     """GB/s of the SAMS-only bandwidth-bound kernels (csrc/sams.hip) at the step's own tensor sizes: stand-alone launches,
     20 repetitions, HIP events on the launch stream, algorithmic bytes per DESIGN.md 3.6, against the 8 TB/s HBM peak."""
@@ -280,9 +290,7 @@ def run_sams(args, trainer, L):
     dom0 = max(range(NKEYS), key=lambda k: ms[k])
     dom, roof = dominant_roofline(
         ms, fl, by, cnt, sams_traffic(KEY_NAMES[dom0]),
-        "profiles/traffic.json [sams]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the kernel's most frequent layer of this step "
-        "(128 -> 256 channels, 256x192, bs = 4) in a single-layer process (tools/one_layer.py; the whole step dies under the "
-        "counters), bytes per launch", "hip events, eager launches in the timed region")
+        sams_traffic_source(), "hip events, eager launches in the timed region")
     for k_ in kernels.values():
         k_["executed_tflops"] = k_["tflops"]
     if "winograd_fused" in kernels:

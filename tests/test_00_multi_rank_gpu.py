@@ -126,3 +126,39 @@ def test_bench_over_a_single_rank_rccl_group(extra, bucketed, two):
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["config"]["exchange"] and line["config"]["exchange_exposed_ms"] is not None, line["config"]
     assert "backend nccl" in p.stderr, p.stderr[-3000:]
+
+
+def test_train_py_and_test_py_entry_points_end_to_end(tmp_path):
+    """`python train.py ...` then `python test.py --checkpoint ...` as the reference's users run them (train.py:32-141,
+    test.py:9-10), on the synthetic dataset: training writes checkpoints/final.ckpt under experiments_dir/name, the test run
+    loads it through load_from_checkpoint + override_hparams and writes the warp-cloth PNGs the next stage reads
+    under result_dir/name/<ckpt>/<datamode>/<Dataset>/.  A run that dies leaves checkpoints/interrupted_by_<Exception>.ckpt
+    and exits non-zero (the reference's save_on_interrupt, train.py:121-137)."""
+    root, res = str(tmp_path / "exp"), str(tmp_path / "res")
+    common = ["--model", "warp", "--dataset", "synthetic", "--name", "cli", "--batch", "2", "--workers", "0", "--synthetic_length", "8"]
+    env = dict(os.environ)
+    p = _run_one([sys.executable, os.path.join(ROOT, "train.py")] + common +
+                 ["--experiments_dir", root, "--keep_epochs", "1", "--decay_epochs", "0", "--limit_train_batches", "3",
+                  "--limit_val_batches", "1", "--val_check_interval", "2"], env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    ckpt = os.path.join(root, "cli", "checkpoints", "final.ckpt")
+    assert os.path.exists(ckpt), os.listdir(os.path.join(root, "cli"))
+    p = _run_one([sys.executable, os.path.join(ROOT, "test.py")] + common + ["--checkpoint", ckpt, "--result_dir", res], env)
+    assert p.returncode == 0 and "Testing........" in p.stdout, p.stderr[-3000:]
+    out = os.path.join(res, "cli", "final.ckpt", "test", "SyntheticDataset")
+    # (warp-mask is only written for VitonDataset: the reference's rule, util/visualization.py:60-88, mirrored in io_png.save_images)
+    assert sorted(os.listdir(out)) == ["warp-cloth"] and len(os.listdir(os.path.join(out, "warp-cloth"))) == 8
+    # a failing run: the exception is logged, the checkpoint carries its name, the exit code is not 0
+    bad = _run_one([sys.executable, "-c",
+                    "import sys; sys.path.insert(0, %r); import shineon_virtual_tryon_amd\n"
+                    "from shineon_virtual_tryon_amd import cli, warp_model\n"
+                    "calls = [0]\n"
+                    "orig = warp_model.WarpModel.training_step\n"
+                    "def boom(self, *a, **k):\n"
+                    "    calls[0] += 1\n"
+                    "    if calls[0] > 8: raise ValueError('injected')\n"
+                    "    return orig(self, *a, **k)\n"
+                    "warp_model.WarpModel.training_step = boom\n"
+                    "sys.exit(cli.main(True, %r))" % (ROOT, common + ["--experiments_dir", root + "2", "--no_shuffle"])], env)
+    assert bad.returncode == 1, (bad.returncode, bad.stderr[-2000:])
+    assert os.path.exists(os.path.join(root + "2", "cli", "checkpoints", "interrupted_by_ValueError.ckpt")), bad.stderr[-2000:]

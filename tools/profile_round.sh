@@ -27,11 +27,11 @@ for PASS in FETCH_SIZE WRITE_SIZE; do
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_wino_fused_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
 done
-# SAMS, the REAL step (bs = 1, one step) with the counters restricted to its dominant kernel (--kernel-include-regex): the
+# SAMS, the REAL step (the timed batch bs = 4, one warm-up + one step) with the counters restricted to its dominant kernel (--kernel-include-regex): the
 # unfiltered passes of rounds 2 and 3 killed the process; if this one survives, traffic.json [sams] comes from the step itself
 for PASS in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_pmc
-  timeout -k 5 420 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "wino_fused_k" -d /tmp/prof_pmc -o r -- python3 $R/bench.py --config sams --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-table > $OUT/${TAG}_pmc_sams_step_$PASS.log 2>&1
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "wino_fused_k" -d /tmp/prof_pmc -o r -- python3 $R/bench.py --config sams --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-table > $OUT/${TAG}_pmc_sams_step_$PASS.log 2>&1
   echo "sams step pmc $PASS rc=$?" >> $OUT/${TAG}_kernel_trace_summary.txt
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   [ -n "$DB" ] && python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_step_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
