@@ -583,3 +583,53 @@ def test_winograd_input_gradient_is_the_flipped_transposed_convolution(cuda, ops
     assert L.so_wino4_conv3x3(dyd.data_ptr(), ko, u4.data_ptr(), None, 0, None, dx4.data_ptr(), c, n, h, w, ko, c, 0, 0.0,
                               wws4.data_ptr(), wws4.numel() * 4, ws.data_ptr(), ws.numel() * 4, st) == 0
     assert_close(dx4, ref.float(), atol=1.5e-5 * float(ref.abs().max()), what="F(4x4,3x3) input gradient")
+
+
+def test_bounded_bucket_wait_returns_on_abort_and_on_deadline(cuda):
+    """The polling wait of the overlapped gradient exchange cannot spin forever: queued behind a signal
+    word that nobody ever stores, it returns when the host sets the abort word (status 1) or when its 100 MHz wall-clock
+    deadline passes (status 2), and a word that IS signalled releases it with status 0."""
+    import ctypes
+    import time
+
+    from shineon_virtual_tryon_amd import lib
+
+    L = lib()
+    flag = L.so_signal_alloc()
+    assert flag
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    comm = torch.cuda.Stream()
+    try:
+        # 1. deadline: 0.05 s, nobody signals
+        words = L.so_hostwords_alloc()
+        w = (ctypes.c_uint32 * 2).from_address(words)
+        assert w[0] == 0 and w[1] == 0
+        t0 = time.time()
+        assert L.so_stream_wait_ge_bounded(flag, 1, words, int(0.05 * 1e8), comm.cuda_stream) == 0
+        comm.synchronize()
+        dt = time.time() - t0
+        assert w[1] == 2 and 0.04 <= dt < 5.0, (w[1], dt)
+        L.so_hostwords_free(words)
+        # 2. abort: a 30 s deadline, released by the host-side abort word within milliseconds
+        words = L.so_hostwords_alloc()
+        w = (ctypes.c_uint32 * 2).from_address(words)
+        assert L.so_stream_wait_ge_bounded(flag, 1, words, int(30 * 1e8), comm.cuda_stream) == 0
+        time.sleep(0.05)
+        assert not comm.query()          # still polling
+        w[0] = 1
+        t0 = time.time()
+        comm.synchronize()
+        assert w[1] == 1 and time.time() - t0 < 2.0, (w[1], time.time() - t0)
+        L.so_hostwords_free(words)
+        # 3. the normal case: counter bumped to 1 and stored into the word by a kernel of another stream
+        words = L.so_hostwords_alloc()
+        w = (ctypes.c_uint32 * 2).from_address(words)
+        assert L.so_stream_wait_ge_bounded(flag, 1, words, int(30 * 1e8), comm.cuda_stream) == 0
+        st = torch.cuda.current_stream().cuda_stream
+        assert L.so_counter_bump(counter.data_ptr(), st) == 0
+        assert L.so_signal_store(flag, counter.data_ptr(), 0, st) == 0
+        comm.synchronize()
+        assert w[1] == 0 and int(counter[0]) == 1
+        L.so_hostwords_free(words)
+    finally:
+        L.so_signal_free(flag)
