@@ -5,7 +5,9 @@
  * reference tree) whose torch op it replaces; INTEGRATION.md shows the ctypes stub a maintainer would
  * add.  Conventions:
  *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; nothing is allocated,
- *     freed or synchronised inside the library; `stream` is a hipStream_t (NULL = default stream);
+ *     freed or synchronised inside the library (three documented exceptions, none on the default path of a step:
+ *     so_signal_alloc's 8-byte signal words, so_hostwords_alloc's pinned abort / status words, and the arrival
+ *     counters of the OPT-IN split-K fix-up, so_igemm_fixup); `stream` is a hipStream_t (NULL = default stream);
  *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative SO_ERR_* code;
  *   - activations are "rows x channels" NHWC matrices: element (pixel p, channel c) lives at
  *     ptr[p * ld + c]; `ld` (floats) may exceed the channel count so that a channel slice of a wider
