@@ -289,7 +289,7 @@ def run_sams(args, trainer, L):
                               "tflops": fl[k] / (ms[k] * 1e-3) / 1e12} for k in range(NKEYS) if cnt[k] > 0}
     dom0 = max(range(NKEYS), key=lambda k: ms[k])
     dom, roof = dominant_roofline(
-        ms, fl, by, cnt, sams_traffic(KEY_NAMES[dom0]),
+        ms, fl, by, cnt, sams_traffic(KEY_NAMES[dom0]) if args.batch == 4 else None,   # (the PMC passes ran at bs = 4)
         sams_traffic_source(), "hip events, eager launches in the timed region")
     for k_ in kernels.values():
         k_["executed_tflops"] = k_["tflops"]
@@ -300,7 +300,7 @@ def run_sams(args, trainer, L):
     mfma_ms = sum(ms) / args.steps
     out = {
         "metric": "SAMS-GAN video frames/sec (three-optimizer step, fwd+bwd+Adam) at 256x192, n_frames=5",
-        "value": world * args.batch * nfr * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "value": world * args.batch * nfr * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp32", "data": "synthetic",
         "config": {"workload": WORKLOADS["sams"], "config": "sams", "launch": "eager (hip events bracket every MFMA launch)",
@@ -401,7 +401,7 @@ def run_c1(args, trainer, L):
     gf_step = GF_PER_FRAME["c1"] * args.batch
     out = {
         "metric": "try-on frames/sec (UnetMaskModel forward only) at 256x192 bs=4",
-        "value": world * args.batch * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "value": world * args.batch * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp32", "data": "synthetic",
         "config": {"workload": WORKLOADS["c1"], "config": "c1", "launch": "eager" if graph is None else "one hipGraph (forward)",
@@ -606,6 +606,26 @@ def hbm_table(dev, batch_size):
     return out
 
 
+def self_launch(n):
+    """`--gpus n` given, no launcher environment: run `python -m torch.distributed.run --nproc-per-node n bench.py <same
+    arguments>` as a child process, pass its stdout (rank 0's JSON line) and stderr through, return its exit code."""
+    import socket
+    import subprocess
+
+    visible = torch.cuda.device_count()   # (counting devices does not initialise the GPU in this process)
+    shared = os.environ.get("SHINEON_LOCAL_DEVICE") is not None   # functional runs: several ranks on one device over gloo
+    if visible < n and not shared:
+        log(f"bench.py: --gpus {n} but only {visible} GPU(s) are visible")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching " + " ".join(cmd[1:]))
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -629,8 +649,21 @@ def main():
                     "and every plan known at the end is written back to it")
     args = ap.parse_args()
 
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        # `python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) and relay rank 0's line.  Decided
+        # here, before this process has made any GPU call - the children are new processes, nothing is exec'ed over a
+        # process that has touched the device.
+        sys.exit(self_launch(args.gpus))
+    if env_world and env_world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
+        sys.exit(2)
+
     trainer = Trainer(graph=not args.no_graph, overlap=True)   # joins the process group under torchrun
     rank, world = trainer.rank, trainer.world
+    if world != args.gpus:   # what the process group itself reports must be what was asked for
+        log(f"bench.py: --gpus {args.gpus} but the process group has {world} ranks")
+        sys.exit(2)
     coll = so_trainer._collective()   # > 1 rank, or the one-rank RCCL group of SHINEON_SINGLE_RANK_GROUP=1 (functional run)
     dev = trainer.device
     L = pkg.lib()
@@ -786,7 +819,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             sect = json.load(open(tpath)).get(cfg, {})   # (the PMC passes see kernel symbols: Winograd-domain GEMMs = gemm_*)
-            traffic = (sect.get(KEY_NAMES[dom0]) or sect.get(KEY_NAMES[dom0].replace("winograd_gemm_", "gemm_"), {})).get("hbm_bytes_per_launch")
+            # bytes per launch scale with the batch: the section only applies to the batch its PMC passes ran at
+            # (`_batch`; sections written before round 5 were taken at the configuration's default batch)
+            if sect.get("_batch", 2 if cfg == "c5" else 4) == args.batch:
+                traffic = (sect.get(KEY_NAMES[dom0]) or sect.get(KEY_NAMES[dom0].replace("winograd_gemm_", "gemm_"), {})).get("hbm_bytes_per_launch")
         dom, roof = dominant_roofline(
             ms, fl, by, cnt, traffic,
             "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch)",
@@ -806,6 +842,7 @@ def main():
             "value": world * args.batch * nfr * args.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": step_ms,
@@ -824,6 +861,9 @@ def main():
                                      else "warp: " + engine.exw.describe() + "; try-on: " + engine.exu.describe()
                                      if cfg == "c4" and getattr(engine, "exu", None) is not None
                                      else "flat slab in 4 buckets after the graph, hidden behind the other model's graph")),
+                       # True: the warp model's BatchNorm running statistics are broadcast in synchronize(), not per step
+                       # (DDP broadcasts per forward; rounds 1-3 timed that broadcast inside the c4 step)
+                       "lazy_buffers": getattr(engine, "lazy_buffers", None) if cfg == "c4" else None,
                        "pipeline_gain_ms": getattr(engine, "pipeline_gain_ms", None) if cfg == "c4" else None,
                        "exchange_probe_ms": getattr(engine, "exchange_ms", None) if cfg == "c4" else None},
             "roofline": {
@@ -833,6 +873,11 @@ def main():
                          "note": "whole step incl. every non-GEMM kernel, Adam and launch gaps: algorithmic FLOPs (SURVEY 8d) / "
                                  "measured step time / fp32-MFMA peak"},
                 "mfma_ms_per_step": mfma_ms, "mfma_time_frac_of_step": mfma_ms / step_ms,
+                # what the matrix pipes really execute per step (every MFMA launch's own 2MNK, the fused Winograd kernel at
+                # 1 / 2.25 of its direct-convolution figure) / step time / peak: the pipe utilisation of the WHOLE step
+                "step_executed_gflop": (sum(fl) - fl[WINOGRAD_KEY] * (1 - 1 / WINOGRAD_FACTOR)) / prof_steps / 1e9,
+                "step_executed_frac": (sum(fl) - fl[WINOGRAD_KEY] * (1 - 1 / WINOGRAD_FACTOR)) / prof_steps / 1e9 / step_ms
+                / PEAK_FP32_MFMA_TFLOPS,
                 "all_mfma_tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0,
                 "all_mfma_executed_tflops": (sum(fl) - fl[WINOGRAD_KEY] * (1 - 1 / WINOGRAD_FACTOR)) / (sum(ms) * 1e-3) / 1e12
                 if sum(ms) > 0 else 0.0,

@@ -5,9 +5,9 @@
  * reference tree) whose torch op it replaces; INTEGRATION.md shows the ctypes stub a maintainer would
  * add.  Conventions:
  *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; nothing is allocated,
- *     freed or synchronised inside the library (three documented exceptions, none on the default path of a step:
- *     so_signal_alloc's 8-byte signal words, so_hostwords_alloc's pinned abort / status words, and the arrival
- *     counters of the OPT-IN split-K fix-up, so_igemm_fixup); `stream` is a hipStream_t (NULL = default stream);
+ *     freed or synchronised inside the library (two documented exceptions, neither on the path of a single-rank step:
+ *     so_signal_alloc's 8-byte signal words and so_hostwords_alloc's pinned abort / status words);
+ *     `stream` is a hipStream_t (NULL = default stream);
  *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative SO_ERR_* code;
  *   - activations are "rows x channels" NHWC matrices: element (pixel p, channel c) lives at
  *     ptr[p * ld + c]; `ld` (floats) may exceed the channel count so that a channel slice of a wider
@@ -145,11 +145,6 @@ int so_igemm_plans_load(const char* path);
  * 2 64x128, 3 128x128, 4 128x128/8 waves, 5 64x128/8 waves, 6 the 4x4x1-MFMA kernels for four-channel convolutions,
  * 7 (group 0) the fused Winograd kernel): summed milliseconds, summed algorithmic FLOPs (2*M*N*K per launch; the fused
  * Winograd kernel: the direct convolution's), launch count.  Returns the number of launches collected and clears the list. */
-/* Split-K summation: 0 (default) - a separate reduce launch; 1 (SHINEON_SPLITK_FIXUP=1 in the environment) - the last block to
- * arrive at an output tile sums the slabs and applies the epilogue inside the GEMM launch (library-owned arrival counters,
- * agent-scope write-through slab traffic).  Both sum the slabs in the same fixed order: results are bit-identical; the fix-up
- * measured 2 % slower on MI355X (private per-XCD L2s; csrc/igemm2.hip has the numbers), hence opt-in. */
-void so_igemm_fixup(int on);
 void so_prof_enable(int on);
 int so_prof_collect(float* out_ms, float* out_flops, int* out_count);
 /* the same + out_bytes[k] (HOST array of 40 doubles; may be NULL): summed ALGORITHMIC HBM bytes of the launches under key k -

@@ -62,8 +62,6 @@ struct SoIgemm {
   int splitk, ktps, nclass;
   int nbias;         // bias entries available (columns >= nbias get no bias: zero channel padding)
   long long sa, sb, sc, sres;  // GEMM batch strides in elements
-  unsigned* cnt;     // split-K fix-up: one arrival counter per (class, output tile), zero on entry and on exit; null = the
-                     // slabs are summed by so_splitk_reduce_kernel instead
 };
 
 // pins memory ops (global, LDS) and MFMAs in source order; VALU/SALU address arithmetic may float across
@@ -133,9 +131,8 @@ __device__ __forceinline__ void so_row_offset(const SoIgemm& p, int cls, int m, 
 }
 
 
-// Sum of the split-K slabs of one output quad in THE fixed order both consumers use (the in-kernel fix-up of the last
-// arriving block and so_splitk_reduce_kernel): groups of eight as ((0+1)+(2+3))+((4+5)+(6+7)), then a group of four, then
-// singles - which block arrives last therefore never changes a bit of the result.
+// Sum of the split-K slabs of one output quad in a fixed order (deterministic): groups of eight as
+// ((0+1)+(2+3))+((4+5)+(6+7)), then a group of four, then singles.
 template <typename vec_t>
 __device__ __forceinline__ vec_t so_sum_slabs(const float* src, int splitk, long long mn) {
   vec_t v = {};
@@ -189,37 +186,6 @@ __device__ __forceinline__ f32x4 so_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]);
   r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
   return r;
-}
-
-constexpr int SO_AUX_SC1 = 16;  // gfx940+ buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1 (agent scope: past the per-XCD L2)
-
-__device__ __forceinline__ f32x4 so_bload_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  const so_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, SO_AUX_SC1);
-  f32x4 r;
-  r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]);
-  r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
-  return r;
-}
-
-// so_sum_slabs (same order, same association) with agent-scope loads: slab s of the quad sits at off + s * slab_bytes
-__device__ __forceinline__ f32x4 so_sum_slabs_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned off, int splitk, unsigned slab_bytes) {
-  f32x4 v = {};
-  int sidx = 0;
-  for (; sidx + 8 <= splitk; sidx += 8) {
-    f32x4 t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = so_bload_sc1(rsrc, off + (unsigned)(sidx + u) * slab_bytes);
-    v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-  }
-  if (sidx + 4 <= splitk) {
-    f32x4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = so_bload_sc1(rsrc, off + (unsigned)(sidx + u) * slab_bytes);
-    v += (t[0] + t[1]) + (t[2] + t[3]);
-    sidx += 4;
-  }
-  for (; sidx < splitk; ++sidx) v += so_bload_sc1(rsrc, off + (unsigned)sidx * slab_bytes);
-  return v;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -302,9 +268,6 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   }
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, (int)p.b_bytes, 0x00020000);
-  // this block's split-K slab (fix-up mode stores through a descriptor to carry the sc1 scope bit)
-  const __amdgpu_buffer_rsrc_t rWs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.ws ? p.ws + (long long)bz * p.M * p.N : nullptr), 0, (int)0x7FFFFFFF, 0x00020000);
 
   // DGRAD parity class constants
   int d_r0 = 0, d_s0 = 0, d_oh = 0, d_ow = 0;
@@ -762,15 +725,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int n = n0 + wn * WTN + j * 32 + col4;
           if (m < p.M && n < p.N) {
             if (to_ws) {
-              if (p.cnt) {
-                // fix-up mode: agent-scope write-through (sc1) - the slab lines go past this XCD's L2 to memory now, so
-                // the block that sums them needs no L2 write-back fence from us
-                so_i32x4 iv;
-                iv[0] = __float_as_int(v[0]); iv[1] = __float_as_int(v[1]); iv[2] = __float_as_int(v[2]); iv[3] = __float_as_int(v[3]);
-                __builtin_amdgcn_raw_buffer_store_b128(iv, rWs, (int)(((unsigned)m * (unsigned)p.N + (unsigned)n) * 4u), 0, SO_AUX_SC1);
-              } else {
-                *reinterpret_cast<f32x4*>(p.ws + ((long long)bz * p.M + m) * p.N + n) = v;
-              }
+              *reinterpret_cast<f32x4*>(p.ws + ((long long)bz * p.M + m) * p.N + n) = v;
             } else {
               long long off, roff;
               so_row_offset<MODE>(p, cls, m, off, roff);
@@ -799,40 +754,6 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           }
         }
         __syncthreads();
-      }
-    }
-    if (to_ws && p.cnt) {
-      // Split-K fix-up without a second launch: every block of this output tile writes its slab; the LAST one to arrive at
-      // the tile's counter sums the slabs in so_sum_slabs' fixed order - the result does not depend on which block that is
-      // - and applies the epilogue.  Cross-XCD visibility WITHOUT fences (an agent-scope release costs a write-back of the
-      // whole per-XCD L2 per block: measured 2x on the step): the slab stores above, the counter atomic and the slab loads
-      // below all carry the agent scope (sc1) themselves - stores write through to memory, loads do not hit stale L2 lines -
-      // and s_waitcnt vmcnt(0) + the barrier order "my slab is out" before "I have arrived".
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      unsigned* flag = reinterpret_cast<unsigned*>(smem);
-      if (tid == 0) {
-        unsigned* c = p.cnt + (unsigned)cls * gx + (unsigned)bx;
-        const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned last = old == (unsigned)p.splitk - 1u ? 1u : 0u;
-        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        flag[0] = last;
-      }
-      __syncthreads();
-      if (flag[0] == 0u) return;
-      const long long mn = (long long)p.M * p.N;
-      const __amdgpu_buffer_rsrc_t rSl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (long long)cls * p.splitk * mn), 0,
-                                                                           (int)0x7FFFFFFF, 0x00020000);
-      constexpr int QPR = BN / 4;
-      for (int q = tid; q < BM * QPR; q += NT) {
-        const int row = q / QPR, col4 = (q - row * QPR) * 4;
-        const int m = m0 + row, n = n0 + col4;
-        if (m >= p.M || n >= p.N) continue;
-        long long off, roff;
-        so_row_offset<MODE>(p, cls, m, off, roff);
-        if (off < 0) continue;
-        const f32x4 v = so_sum_slabs_sc1(rSl, ((unsigned)m * (unsigned)p.N + (unsigned)n) * 4u, p.splitk, (unsigned)(mn * 4));
-        so_epilogue_quad<MODE>(p, v, off, roff, n);
       }
     }
     return;
@@ -1005,46 +926,6 @@ void so_prof_end(int slot, hipStream_t stream) {
   if (slot >= 0 && slot < (int)g_prof.size()) (void)hipEventRecord(g_prof[slot].e1, stream);
 }
 
-// ---- split-K fix-up counters -----------------------------------------------------------------------------------------
-// OPT-IN (SHINEON_SPLITK_FIXUP=1 / so_igemm_fixup(1)); the default is the separate reduce launch.  Measured on MI355X, round 4
-// (bench.py, plans re-measured for each mode; bit-identical results, tests/test_ops_gpu.py):
-//     reduce kernel   c4 612.7 frames/s   c2 1615     <- default
-//     in-kernel fix-up, agent-scope fences (release = write-back of the whole per-XCD L2, per block)     c4 342.6   c2 797
-//     in-kernel fix-up, sc1 (agent-scope, write-through) slab stores / loads and no fence                c4 599.3   c2 1581
-// The 8 XCDs have private L2s: anything one block hands to another inside a launch has to go through memory (write-through
-// stores are slower than the write-back ones the reduce kernel's producers use), and the last block of a tile sums its slabs
-// alone while the reduce kernel spreads the same work over every CU.  65 saved launches per step (~4 us each) do not pay for it.
-//
-// One zeroed ring of arrival counters owned by the library (hipMalloc; allocated at the first split-K launch outside a stream
-// capture - every engine runs one eager step before it captures).  Each launch takes the next `n` counters of the ring; the
-// kernel leaves them zero again, and the ring (4 Mi counters, ~6 training steps of this path) is far longer than anything in
-// flight, so a launch never meets the counters of a kernel that is still running.  Captured launches keep the offsets they
-// were captured with.
-static unsigned* g_cnt_ring = nullptr;
-static long long g_cnt_cursor = 0;
-constexpr long long kCntRing = 1ll << 22;
-static int g_fixup = -1;
-
-static unsigned* so_fixup_counters(long long n, hipStream_t stream) {
-  if (n <= 0 || n > kCntRing) return nullptr;
-  if (!g_cnt_ring) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &cap);
-    if (cap != hipStreamCaptureStatusNone) return nullptr;       // no allocation inside a capture: reduce kernel this time
-    void* ptr = nullptr;
-    if (hipMalloc(&ptr, (size_t)kCntRing * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(ptr, 0, (size_t)kCntRing * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-      (void)hipFree(ptr);
-      return nullptr;
-    }
-    g_cnt_ring = (unsigned*)ptr;
-  }
-  if (g_cnt_cursor + n > kCntRing) g_cnt_cursor = 0;
-  unsigned* out = g_cnt_ring + g_cnt_cursor;
-  g_cnt_cursor += n;
-  return out;
-}
-
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
   SoIgemm p = p_in;
@@ -1066,8 +947,6 @@ static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
                     (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
                     (!p.res || ((p.ldres & 3) == 0 && so_aligned16(p.res) && (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
                     (!p.gate || so_aligned16(p.gate));
-  p.cnt = (p.splitk > 1 && wide && g_fixup > 0 && (long long)p.splitk * p.M * p.N * 4 < 0x7FFFFFF0LL)
-              ? so_fixup_counters(tiles * p.nclass, stream) : nullptr;
   SoProfRec rec;
   bool timed = g_prof_on;
   if (timed) {
@@ -1096,7 +975,7 @@ static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
   }
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
-  if (p.splitk > 1 && !p.cnt) {   // (with counters the last block of every tile has already summed the slabs)
+  if (p.splitk > 1) {
     const long long total = (long long)p.nclass * p.M * p.N;
     int blocks = so_cdiv(wide ? total / 4 : total, 256);
     if (blocks > 4096) blocks = 4096;
@@ -1284,14 +1163,7 @@ void so_igemm_tile_cost(float c64x64, float c128x64, float c64x128, float c128x1
   g_tile_cost[0] = c64x64; g_tile_cost[1] = c128x64; g_tile_cost[2] = c64x128; g_tile_cost[3] = c128x128;
 }
 
-void so_igemm_autotune(int on) {
-  g_autotune = on;
-  if (g_fixup < 0) {
-    const char* e = getenv("SHINEON_SPLITK_FIXUP");
-    g_fixup = (e && e[0] == '1') ? 1 : 0;
-  }
-}
-void so_igemm_fixup(int on) { g_fixup = on ? 1 : 0; }
+void so_igemm_autotune(int on) { g_autotune = on; }
 int so_igemm_plan_count(void) { return (int)g_plan_cache.size(); }
 
 // Plan cache persistence (one text line per shape: 12 key ints, then bm bn splitk ktps).  Returns the number

@@ -89,10 +89,6 @@ def workspace(device, min_bytes=0, lane=0):
 
 
 _SIDE = {}
-# Weight/bias gradients on a side stream, overlapping the input-gradient GEMM.  Measured on MI355X (bench.py, graph
-# replay): 352 frames/s with, 361 without - both GEMMs already fill the CUs and the fork/join adds kernel boundaries.
-# Off by default; SHINEON_CONCURRENT_WGRAD=1 switches it on for experiments.
-CONCURRENT_WGRAD = os.environ.get("SHINEON_CONCURRENT_WGRAD", "0") == "1"
 # Input gradients of trainable convolutions read the OHWI weights in place (the engine transposes while staging);
 # SHINEON_DGRAD_IN_PLACE=0 goes back to a transposed copy per step (measured 0.05 ms/step slower).  The frozen VGG
 # chain always uses cached transposed weights.
@@ -444,11 +440,6 @@ class _Conv2dFn(torch.autograd.Function):
                         db_ = dbp[:o]
             return dw_, db_
 
-        fork = None
-        if CONCURRENT_WGRAD and ctx.needs_input_grad[0] and (need_w or need_b):
-            fork = _SideStream(dev)
-            with fork:
-                dw, db = weight_grads(lane=1)
         if ctx.needs_input_grad[0]:
             ws = workspace(dev)
             dxp = nhwc_empty(n, h, wd, cp, dev)
@@ -475,9 +466,7 @@ class _Conv2dFn(torch.autograd.Function):
                     "conv2d_dgrad_t",
                 )
             dx = dxp if cp == i else dxp[:, :i]
-        if fork is not None:
-            fork.join()
-        elif need_w or need_b:
+        if need_w or need_b:
             dw, db = weight_grads(lane=0)
         grad_ready(w_direct, b_direct)   # both the input- and the weight-gradient kernels of this layer are in the stream
         return dx, dw, db, None, None, None, None, None, None, None

@@ -181,11 +181,13 @@ class BucketedExchange:
         self.expected = None        # {id(param): reports per backward pass}, from the calibration pass
         self.order = None           # bucket indices in the order they became ready in the calibration pass
         self._count, self._signalled, self._calib_order = {}, set(), []
+        self._streams = {}          # bucket -> {stream handle: torch stream} the bucket's gradient kernels were issued on
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_ready) for p, _, _ in table]
         self.step_no = 0
         self._launched = False
         self._armed = False
         self._launched_step = 0     # step_no of the last launch(): launch() must follow a newly enqueued step
+        self.failed = False         # set when the owning engine's __call__ raised: no further launch()
         # [abort request, waiter status]: pinned host words the polling kernels read / write (include/shineon_hip.h)
         self.words = self.L.so_hostwords_alloc()
         if not self.words:
@@ -207,8 +209,10 @@ class BucketedExchange:
             pass
 
     def abort(self):
-        """Exception path: release every polling wait that is queued or running (they return within ~64 polls) so that neither
-        this process nor a peer inside the collective behind the wait hangs.  The exchange is unusable afterwards."""
+        """Emergency release of every polling wait that is queued or running (they return within ~64 polls), for a caller that
+        KNOWS a bucket's signal node will never run.  The all-reduce + Adam behind a released wait then run on whatever the
+        gradient slab holds (check_status() / exchange_statuses() report it); the exchange is unusable afterwards.  The step
+        engines do not call this on ordinary exceptions (see _abort_exchanges_on_error)."""
         if self._words is not None:
             self._words[0] = 1
 
@@ -236,6 +240,7 @@ class BucketedExchange:
         if not torch.cuda.is_current_stream_capturing():
             self.step_no += 1           # the device counter advances when the bump EXECUTES: now, or at every graph replay
         self._count, self._signalled, self._calib_order = {}, set(), []
+        self._streams = {}
         ops._GRAD_READY[0] = self._on_ready
         self._armed = True
 
@@ -244,6 +249,8 @@ class BucketedExchange:
         if b is None or not self._armed:   # (the autograd hooks also fire in backward passes this engine does not drive)
             return
         self._count[id(p)] = self._count.get(id(p), 0) + 1
+        cur = torch.cuda.current_stream()
+        self._streams.setdefault(b, {})[cur.cuda_stream] = cur   # the reporting operator's kernels are in THIS stream
         if self.expected is None or b in self._signalled:
             if self.expected is None and (not self._calib_order or self._calib_order[-1] != b):
                 self._calib_order.append(b)
@@ -252,6 +259,18 @@ class BucketedExchange:
             self._signal(b)
 
     def _signal(self, b):
+        # A bucket may hold gradients produced on several streams (WarpModel.tower_streams runs the cloth tower - forward and,
+        # through autograd, backward - on a forked stream; a bucket is a contiguous slab range and can straddle both towers).
+        # The signal is a kernel on ONE stream: it first waits for everything the other reporting streams have been given so
+        # far (all of the bucket's reports are in by now, each made after its kernels were launched), eagerly and as graph
+        # edges under capture.  Without this the communication stream could reduce and update a bucket whose other tower's
+        # weight-gradient kernels are still writing it.
+        cur = torch.cuda.current_stream()
+        for handle, st in self._streams.get(b, {}).items():
+            if handle != cur.cuda_stream:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
         self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), int(self.wait_mode == 0), self._stream()),
                     "signal_store")
         self._signalled.add(b)
@@ -269,7 +288,6 @@ class BucketedExchange:
             names = {id(p): i for i, (p, _, _) in enumerate(self.opt.slot_table())}
             diff = [(names.get(k, -1), self.expected.get(k, 0), self._count.get(k, 0))
                     for k in set(self.expected) | set(self._count) if self.expected.get(k, 0) != self._count.get(k, 0)]
-            self.abort()
             raise RuntimeError(f"BucketedExchange: {len(diff)} parameters reported their gradient another number of times than in "
                                f"the calibration pass (slot, expected, seen): {sorted(diff)[:8]} - a bucket may have been released "
                                "before its gradients were complete; call recalibrate() if the pass structure changed on purpose")
@@ -293,6 +311,8 @@ class BucketedExchange:
     # ---- after the step has been launched ----------------------------------------------------------------------------
     def launch(self, grad_scale_extra=1.0):
         """Queue wait -> all-reduce -> Adam per bucket on the communication stream.  Non-blocking for the host with RCCL."""
+        if self.failed:
+            raise RuntimeError("BucketedExchange: the step engine raised earlier; rebuild the engine")
         if self.step_no <= self._launched_step:
             raise RuntimeError("BucketedExchange.launch() without a newly enqueued step (begin() / note_replay() since the last "
                                "launch): the polling wait would be queued ahead of the kernels that release it")
@@ -327,9 +347,16 @@ class BucketedExchange:
 
 
 def _abort_exchanges_on_error(method):
-    """Any exception escaping a step engine's __call__ first releases every bounded wait its exchanges have queued (so the
-    communication streams - and peers inside the collectives behind those waits - are not left spinning), then propagates;
-    the process is expected to exit non-zero (Trainer.fit saves its interrupt checkpoint first)."""
+    """An exception escaping a step engine's __call__ marks its exchanges failed (no further launch()) and propagates; the
+    process is expected to exit non-zero (Trainer.fit saves its interrupt checkpoint first).
+
+    It does NOT set the abort word: every bounded wait that launch() has queued belongs to a step whose signal nodes were
+    all enqueued before it (launch() refuses anything else), so those waits are released by the device on their own and
+    the all-reduce + Adam behind them run on COMPLETE gradients.  Aborting them - what this wrapper did before - released
+    the previous, correctly enqueued step early whenever a host-side error hit the next one (bad batch, a failing buffer
+    broadcast) and let Adam run on partial gradients right before the interrupt checkpoint was written.  A wait whose
+    signal really never runs (a graph launch that failed asynchronously) ends at its wall-clock deadline with status 2;
+    BucketedExchange.abort() stays available for a caller that knows the producer will never run."""
     import functools
 
     @functools.wraps(method)
@@ -339,10 +366,22 @@ def _abort_exchanges_on_error(method):
         except BaseException:
             for ex in self._all_exchanges():
                 if ex is not None:
-                    ex.abort()
+                    ex.failed = True
             raise
 
     return wrapped
+
+
+def exchange_statuses(step):
+    """Status words of every bucketed exchange of a step engine after the device has been synchronised: {} when all waits
+    completed normally, else {exchange index: 1 (aborted) | 2 (deadline)} - the parameters / moments then hold an update made
+    from incomplete gradients."""
+    out = {}
+    for i, ex in enumerate(getattr(step, "_all_exchanges", lambda: ())()):
+        code = int(ex._words[1]) if ex is not None and ex._words is not None else 0
+        if code:
+            out[i] = code
+    return out
 
 
 def _make_exchange(optimizer, bucketed, bucket_bytes, group=None):
@@ -811,7 +850,13 @@ class ChainedTrainStep:
 
     def synchronize(self):
         """Everything in flight lands; with lazy buffer broadcast this is also where rank 0's BatchNorm running statistics
-        reach the other ranks (call it before validation / a checkpoint / reading the buffers)."""
+        reach the other ranks (call it before validation / a checkpoint / reading the buffers).
+
+        COLLECTIVE with several ranks (`lazy_buffers`): every rank must call it, in the same place - called on a subset of
+        the ranks it deadlocks inside the broadcast.  After only flush() / torch.cuda.synchronize() the warp model's
+        running_mean / running_var are still this rank's own; a rank-0-only checkpoint or validation path must go through
+        synchronize() on ALL ranks first (Trainer.fit_chained does).  The per-step broadcast DDP pays is therefore not in
+        bench.py's timed c4 region: the line says so in `config.lazy_buffers`."""
         self.flush()
         if self.exw is not None:
             self.exw.finish()
@@ -1121,7 +1166,12 @@ class Trainer:
             except Exception:  # noqa: BLE001 - the original error is the one to report
                 logger.exception("flush before the failure checkpoint failed; the checkpoint may lag one step")
             torch.cuda.synchronize()
-            self.save_checkpoint(osp.join(ckpt_dir, f"interrupted_by_{type(e).__name__}.ckpt"))
+            bad = exchange_statuses(step) if step is not None else {}
+            if bad:   # a bucket wait was aborted / timed out: Adam ran on incomplete gradients - say so in the file name
+                logger.error("gradient-bucket waits ended abnormally %s: the weights / moments of the last step are NOT a valid "
+                             "training state; writing the checkpoint as *.incomplete_exchange.ckpt", bad)
+            self.save_checkpoint(osp.join(ckpt_dir, f"interrupted_by_{type(e).__name__}" +
+                                          (".incomplete_exchange" if bad else "") + ".ckpt"))
             raise
         finally:
             signal.signal(signal.SIGINT, previous)

@@ -25,7 +25,7 @@ from shineon_virtual_tryon_amd.warp_model import WarpModel  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
-def run(which, graph):
+def run(which, graph, bucket_bytes=16 << 20):
     torch.manual_seed(5)
     if which == "unet":
         model = UnetMaskModel(make_namespace(self_attn=True, activation="gelu", allow_random_vgg=True, lr=1e-3))
@@ -36,11 +36,14 @@ def run(which, graph):
     (opt,), _ = model.configure_optimizers()
     trainer.broadcast_parameters(model, optimizer=opt)
     batches = [synthetic_batch(2, dev, smooth=True, start=2 * i) for i in range(3)]
-    eng = trainer.TrainStep(model, opt, batches[0], graph=graph, overlap=True, bucket_bytes=16 << 20)
+    eng = trainer.TrainStep(model, opt, batches[0], graph=graph, overlap=True,
+                            **({} if bucket_bytes is None else {"bucket_bytes": bucket_bytes}))
     for b in batches:
         eng(b)
     eng.flush()
     torch.cuda.synchronize()
+    if which == "warp":
+        assert model.tower_streams, "the stand-alone WarpModel runs its two extraction towers on two streams by default"
     return opt, eng
 
 
@@ -63,6 +66,9 @@ def run_chained(bucketed):
 os.environ["SHINEON_SINGLE_RANK_GROUP"] = "0"
 chained_plain, _ = run_chained(False)
 plain = {(w, g): run(w, g) for w in ("unet", "warp") for g in (True, False)}
+# the DEFAULT bucket size (64 MB): the warp model's 76 MB slab falls into two buckets, and the first one holds all of
+# extractionA plus the first layers of extractionB - gradients produced on BOTH tower streams (BucketedExchange._signal)
+plain.update({("warp", g, None): run("warp", g, None) for g in (True, False)})
 assert all(e.exchange is None for _, e in plain.values()) and not trainer._collective()
 
 os.environ["SHINEON_SINGLE_RANK_GROUP"] = "1"
@@ -77,6 +83,10 @@ for key, (o0, _) in plain.items():
     o1, e1 = run(*key)
     assert e1.exchange is not None and e1.exchange.active and len(e1.exchange.buckets) >= 2, key
     print(key, e1.exchange.describe(), flush=True)
+    if len(key) == 3:   # default bucket size: at least one bucket's gradients come from more than one stream
+        multi = [b for b, st in e1.exchange._streams.items() if len(st) > 1]
+        assert multi, ("no bucket straddles the two tower streams - the test no longer covers the multi-stream signal", key)
+        print(key, "buckets fed by several streams:", multi, flush=True)
     assert o1._steps == o0._steps == 3
     for a, b in zip(o1._flat, o0._flat):
         if a is o1._flat[1]:

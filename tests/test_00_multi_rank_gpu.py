@@ -86,6 +86,24 @@ def test_bench_multi_rank_code_path_two_ranks_on_one_gpu(extra, tmp_path):
     assert not [ln for ln in res[1][1].splitlines() if ln.startswith("{")]   # only rank 0 prints the JSON line
 
 
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself (fresh child processes
+    through torch.distributed.run, decided before the parent touches the GPU) and relay rank 0's line - not silently
+    benchmark one GPU.  Both ranks on cuda:0 over gloo here (SHINEON_LOCAL_DEVICE also tells bench.py that ranks may share a
+    device)."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SHINEON_DIST_BACKEND="gloo", SHINEON_LOCAL_DEVICE="0", GLOO_SOCKET_IFNAME="lo", SHINEON_DIST_TIMEOUT_S="120")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-hbm-table", "--config", "c2"]
+    p = _run_one(cmd, env)
+    assert p.returncode == 0, p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1   # only rank 0 prints
+
+
 def test_single_rank_rccl_group_runs_the_exchange_path():
     """RCCL itself on the 1-GPU box: a one-rank nccl group (SHINEON_SINGLE_RANK_GROUP=1) with every collective of
     trainer.TrainStep issued for real - bucketed all-reduce on the communication stream behind the in-graph signal nodes,

@@ -581,3 +581,20 @@ def test_documented_test_command_lines_load_the_checkpoint_and_override_hparams(
     if model == "unet_mask":   # architecture flags came from the CHECKPOINT (the test command line does not repeat them)
         assert any("query_conv" in k for k in net.state_dict())
     assert cli.train_kwargs(opt) == {}
+
+
+def test_bench_gpus_flag_must_match_the_launched_world():
+    """`bench.py --gpus N` means N: under a launcher that started another number of ranks it exits non-zero before
+    anything touches the GPU; without a launcher and with fewer than N visible GPUs it refuses instead of silently timing
+    one GPU (the self-launch itself runs on the GPU box: tests/test_00_multi_rank_gpu.py)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SHINEON_LOCAL_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=170)
+    assert p.returncode == 2 and "WORLD_SIZE=3" in p.stderr, (p.returncode, p.stderr[-800:])
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True,
+                       timeout=170)
+    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr and not p.stdout.strip(), (p.returncode, p.stderr[-800:])

@@ -90,44 +90,6 @@ def test_conv2d_fwd_bwd(ops, cuda, case, force):
         lib().so_igemm_force(0, 0, 0)
 
 
-@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[2], CONV_CASES[3], CONV_CASES[6], (2, 64, 33, 24, 96, 3, 1, 1)])
-@pytest.mark.parametrize("force", [(64, 64, 4), (128, 128, 2), (64, 128, 8), (128, 64, 3)])
-def test_splitk_in_kernel_fixup_is_bit_identical_to_the_reduce_kernel(ops, cuda, case, force):
-    """Split-K summed by the last arriving block inside the GEMM launch (library-owned arrival counters, opt-in) against
-    the separate so_splitk_reduce_kernel launch: same slabs, same fixed summation order -> torch.equal on the forward
-    output, the input gradient and the weight gradient (fprop / dgrad incl. stride classes / wgrad), run twice so that the
-    self-resetting counters are exercised."""
-    from shineon_virtual_tryon_amd import lib
-
-    n, ci, h, w, co, k, s, p = case
-    x = rnd(n, ci, h, w, seed=1).to(cuda)
-    wt = rnd(co, ci, k, k, seed=2, scale=(2.0 / (ci * k * k)) ** 0.5).to(cuda)
-    b = rnd(co, seed=3, scale=0.1).to(cuda)
-    g = None
-
-    def run():
-        nonlocal g
-        xi, wi, bi = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        y = ops.conv2d(xi, wi, bi, s, p)
-        if g is None:
-            g = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(cuda)
-        y.backward(ops.to_rows(g) if hasattr(ops, "to_rows") else g)
-        torch.cuda.synchronize()
-        return [t.detach().contiguous().clone() for t in (y, xi.grad, wi.grad, bi.grad)]
-
-    lib().so_igemm_force(*force)
-    try:
-        lib().so_igemm_fixup(0)
-        ref = run()
-        lib().so_igemm_fixup(1)
-        for rep in range(2):
-            for name, a, r in zip(("y", "dx", "dw", "db"), run(), ref):
-                assert torch.equal(a, r), (case, force, rep, name, float((a - r).abs().max()))
-    finally:
-        lib().so_igemm_fixup(0)   # the library default (csrc/igemm2.hip: the fix-up measured slower on this chip)
-        lib().so_igemm_force(0, 0, 0)
-
-
 @pytest.mark.parametrize("waves", [8])
 def test_conv2d_other_wave_counts(ops, cuda, waves):
     """The 8-wave 128x128 tile, forced (the measured plans pick it per shape)."""

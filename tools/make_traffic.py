@@ -1,6 +1,6 @@
 """HBM traffic per launch of every MFMA kernel instantiation from two rocprofv3 PMC passes of bench.py.
 
-    python tools/make_traffic.py <tag>_FETCH_SIZE_pmc.csv <tag>_WRITE_SIZE_pmc.csv profiles/traffic.json [config]
+    python tools/make_traffic.py <tag>_FETCH_SIZE_pmc.csv <tag>_WRITE_SIZE_pmc.csv profiles/traffic.json [config] [batch]
 
 `config` (c4 / c2 / c3 / sams, default c4) selects the section of traffic.json that is replaced; bench.py reads the section
 of the configuration it runs.
@@ -40,7 +40,7 @@ def load(path, col):
     return out
 
 
-def main(fetch_csv, write_csv, out_json, config="c4"):
+def main(fetch_csv, write_csv, out_json, config="c4", batch=None):
     import os
 
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
@@ -49,7 +49,9 @@ def main(fetch_csv, write_csv, out_json, config="c4"):
         allcfg = {}
     allcfg["_doc"] = ("HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE), KiB -> bytes; "
                       "one section per bench.py --config")
-    res = {"_sources": [fetch_csv.split("/")[-1], write_csv.split("/")[-1]]}
+    # `_batch`: frames per GPU of the profiled command; bench.py reports `roofline.traffic` only for a run at that batch
+    res = {"_sources": [fetch_csv.split("/")[-1], write_csv.split("/")[-1]],
+           "_batch": int(batch) if batch is not None else (2 if config == "c5" else 4)}
     for k in sorted(f):
         fk = f[k][1] / f[k][0]
         wk = w[k][1] / w[k][0] if k in w else 0.0
@@ -57,8 +59,8 @@ def main(fetch_csv, write_csv, out_json, config="c4"):
                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
     allcfg[config] = res
     json.dump(allcfg, open(out_json, "w"), indent=1)
-    print(f"{len(res) - 1} instantiations -> {out_json} [{config}]")
+    print(f"{len(res) - 2} instantiations -> {out_json} [{config}]")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
