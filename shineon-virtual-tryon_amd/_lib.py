@@ -10,7 +10,8 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libshineon_hip.so")
+# SHINEON_LIB: another build of the library (measurement variants of tools/ablate_igemm.sh); the product path is the default
+LIB_PATH = os.environ.get("SHINEON_LIB") or os.path.join(_HERE, "libshineon_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "shineon_hip.h")
 
 # Measured igemm plans (tile, waves, split-K per layer shape) committed with the package: loaded at library load so

@@ -200,20 +200,36 @@ __device__ __forceinline__ int so_swz(int row) {
   return ((row >> 2) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 1) ^ (row >> 4)) & 1) << 2);
 }
 
+// Two dwords from two UNRELATED registers to two consecutive LDS dwords in one instruction.  The transposed staging writes
+// (k, k+1) of one tile row, whose values sit in two different 16-byte load results: as a ds_write_b64 / b128 the pair has to
+// be assembled in adjacent registers first, and hipcc then rotates whole register stages with v_mov copies behind a
+// vmcnt(0) (seen in the ISA of every MC instantiation: it defeats the load pipeline).  ds_write2_b32 takes any two
+// registers and costs the same LDS issue time as ds_write_b64 (three source dwords).  The compiler does not count inline-asm
+// LDS operations: the K loop drains them with an explicit lgkmcnt(0) in front of its barrier (SO_SYNC).
+__device__ __forceinline__ void so_ds_write2(unsigned lds_addr, float a, float b) {
+  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(lds_addr), "v"(a), "v"(b) : "memory");
+}
+__device__ __forceinline__ void so_ds_write2_hi(unsigned lds_addr, float a, float b) {
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" : : "v"(lds_addr), "v"(a), "v"(b) : "memory");
+}
+__device__ __forceinline__ void so_ds_write1(unsigned lds_addr, float a) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"(lds_addr), "v"(a) : "memory");
+}
+
+// `tile_addr`: LDS byte address of the stage (the low 32 bits of a __shared__ pointer are its LDS offset)
 template <int J>
-__device__ __forceinline__ void so_store_transposed(float* tile, const int (&addr)[4], const f32x4 (&q)[J]) {
+__device__ __forceinline__ void so_store_transposed(unsigned tile_addr, const int (&addr)[4], const f32x4 (&q)[J]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float* d = tile + addr[i];
+    const unsigned d = tile_addr + (unsigned)addr[i] * 4u;
     if constexpr (J == 4) {
-      f32x4 w; w[0] = q[0][i]; w[1] = q[1][i]; w[2] = q[2][i]; w[3] = q[3][i];
-      *reinterpret_cast<f32x4*>(d) = w;
+      so_ds_write2(d, q[0][i], q[1][i]);
+      so_ds_write2_hi(d, q[2][i], q[3][i]);
     } else if constexpr (J == 2) {
-      f32x2 w; w[0] = q[0][i]; w[1] = q[1][i];
-      *reinterpret_cast<f32x2*>(d) = w;
+      so_ds_write2(d, q[0][i], q[1][i]);
     } else {
       static_assert(J == 1, "1, 2 or 4 quads per thread");
-      d[0] = q[0][i];
+      so_ds_write1(d, q[0][i]);
     }
   }
 }
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int hi = a_h0[j] + (int)r, wi = a_w0[j] + (int)s;
           const bool ok = kvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
         }
       } else if constexpr (MODE == MODE_DGRAD) {
         unsigned tapi, ko, tr, ts;
@@ -461,13 +477,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int ho = a_h0[j] - (int)tr, wo = a_w0[j] - (int)ts;
           const bool ok = kvalid & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
-          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + tap_off) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
         }
       } else {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
           const bool ok = kvalid & (a_h0[j] == 0);
-          dst[j] = so_bload(rA, ok ? (unsigned)(a_org[j] + (int)kk) * 4u : SO_OOB);
+          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + (int)kk) * 4u) | (ok ? 0u : SO_OOB)));
         }
       }
     } else {
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j) {
         const int kk = k0 + a_kr * AJ + j;
         const bool ok = colok & (kk < Klim);
-        dst[j] = so_bload(rA, ok ? (unsigned)(kk * p.lda + col) * 4u : SO_OOB);
+        dst[j] = so_bload(rA, (((unsigned)(kk * p.lda + col) * 4u) | (ok ? 0u : SO_OOB)));
       }
     }
   };
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const bool ok = kvalid & (b_row[j] >= 0);
-        dst[j] = so_bload(rB, ok ? (unsigned)(b_row[j] + koff) * 4u : SO_OOB);
+        dst[j] = so_bload(rB, (((unsigned)(b_row[j] + koff) * 4u) | (ok ? 0u : SO_OOB)));
       }
     } else {
       const int col = n0 + b_mq * 4;
@@ -516,13 +532,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
             const int r = d_r0 + p.stride * u_cur_r, s = d_s0 + p.stride * u_cur_s;
             const int ko = u_cur_c0 + b_kr * BJ + j;
             const bool ok = (kk < Klim) & (col < p.N);
-            dst[j] = so_bload(rB, ok ? (unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+            dst[j] = so_bload(rB, (((unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
             continue;
           }
           // in-place OHWI weights: k row kk = (class tap (tr, ts), ko), carried incrementally like the WGRAD pixel
           const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
-          dst[j] = so_bload(rB, ok ? (unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, (((unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
           if (j + 1 < BJ) {
             dg_ko += 1;
             const bool c1 = dg_ko == p.Ko;
@@ -545,7 +561,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int hi = wg_ho * p.stride - p.pad + w_r;
           const int wi = wg_wo * p.stride - p.pad + w_s;
           const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          dst[j] = so_bload(rB, ok ? (unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, (((unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u) | (ok ? 0u : SO_OOB)));
           if (j + 1 < BJ) {  // next k row = next output pixel
             wg_wo += 1;
             const bool cw = wg_wo == p.Wo;
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           }
         } else {
           const bool ok = (kk < Klim) & (col < p.N);
-          dst[j] = so_bload(rB, ok ? (unsigned)(kk * p.ldb + col) * 4u : SO_OOB);
+          dst[j] = so_bload(rB, (((unsigned)(kk * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
         }
       }
     }
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j)
         *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
     } else {
-      so_store_transposed<AJ>(as, a_st, src);
+      so_store_transposed<AJ>((unsigned)(uintptr_t)as, a_st, src);
     }
   };
   auto store_b = [&](int st, const f32x4 (&src)[BJ]) {
@@ -588,7 +604,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < BJ; ++j)
         *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
     } else {
-      so_store_transposed<BJ>(bs, b_st, src);
+      so_store_transposed<BJ>((unsigned)(uintptr_t)bs, b_st, src);
     }
   };
 
@@ -651,47 +667,143 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     }
   };
 
-  // prologue: the loads of tiles 0 and 1 are issued back to back (one exposed memory latency instead of two),
-  // tile 0 -> LDS[0]; tile 1 stays in flight in registers
+#ifndef SO_ABLATE
+#define SO_ABLATE 0
+#endif
+  // SO_ABLATE (tools/ablate_igemm.sh, measurement builds only; results are WRONG for any non-zero value): drop one ingredient
+  // of the K loop to see what the loop is bound by - 1: MFMAs, 2: LDS stores, 4: global loads, 8: the barrier, 16: LDS reads.
+#if SO_ABLATE & 16
+#define SO_READ_FRAG(...)
+#else
+#define SO_READ_FRAG(...) read_frag(__VA_ARGS__)
+#endif
+#if SO_ABLATE & 1
+#define SO_MMA(a, b) do { _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) \
+    acc[i_][j_][0] += a[i_][0] * b[j_][0] + a[i_][1] * b[j_][1] + a[i_][2] * b[j_][2] + a[i_][3] * b[j_][3]; } while (0)
+#else
+#define SO_MMA(a, b) mma(a, b)
+#endif
+#if SO_ABLATE & 2
+#define SO_STORE_A(st, r) asm volatile("" :: "v"(r[0][0]), "v"(r[AJ - 1][3]))
+#define SO_STORE_B(st, r) asm volatile("" :: "v"(r[0][0]), "v"(r[BJ - 1][3]))
+#else
+#define SO_STORE_A(st, r) store_a(st, r)
+#define SO_STORE_B(st, r) store_b(st, r)
+#endif
+#if SO_ABLATE & 4
+#define SO_LOAD_A(kt, r)
+#define SO_LOAD_B(kt, r)
+#else
+#define SO_LOAD_A(kt, r) load_a(kt, r)
+#define SO_LOAD_B(kt, r) load_b(kt, r)
+#endif
+#if SO_ABLATE & 8
+#define SO_SYNC()
+#else
+// (transposed staging writes are inline asm, invisible to the compiler's waitcnt insertion: drain them by hand)
+#define SO_SYNC() do { if constexpr (A_MC || B_MC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#endif
+
+  // Software pipeline, TWO register stages (round 5; tiles with one or two accumulators per wave).  While tile t is multiplied out of LDS[t & 1], tile t+1 goes from its
+  // register stage into LDS[(t+1) & 1] and the loads of tile t+3 are issued into the stage it has just vacated; tile t+2 is
+  // in flight in the other stage.  A global load therefore has TWO whole K tiles (32+ MFMAs per wave, >= 2000 cycles) to
+  // land before its ds_write needs it.  Round 1-4 ordering for the record: ONE stage, loads issued behind the third / fourth
+  // MFMA group of tile t and consumed behind the first / second group of tile t+1 - 8 MFMAs = 512 cycles of cover against an
+  // L2 latency of 500-900 cycles under load; the ISA showed `s_waitcnt vmcnt(3..0)` in front of every ds_write (and a
+  // vmcnt(0) on the loop's back edge in the weight-gradient kernels), and the ablation builds (profiles/r05_igemm_ablation.txt)
+  // put 10-25 % of the kernel time on exactly those waits.  The loop is unrolled by two so that both stages and both LDS
+  // buffers are addressed statically; the loaders still see the tiles in order (their incremental index state relies on it).
+  // The 128x128 / 4-wave tile (four accumulators per wave, 160+ VGPRs) has no room for a second stage: it keeps ONE stage
+  // with the same early issue point (behind the first / second MFMA group), i.e. one whole K tile of cover.
+  constexpr bool TWO_STAGE = NW == 4 && TM * TN <= 2;   // (8-wave tiles: two blocks per CU need <= 128 VGPRs)
+  f32x4 ra1[TWO_STAGE ? AJ : 1], rb1[TWO_STAGE ? BJ : 1];
+  (void)ra1; (void)rb1;
   {
     f32x4 ra0[AJ], rb0[BJ];
     load_a(kt_begin, ra0);
     load_b(kt_begin, rb0);
     load_a(kt_begin + 1, ra);
     load_b(kt_begin + 1, rb);
+    if constexpr (TWO_STAGE) {
+      load_a(kt_begin + 2, ra1);
+      load_b(kt_begin + 2, rb1);
+    }
     store_a(0, ra0);
     store_b(0, rb0);
   }
+#if SO_ABLATE & 16
+  read_frag(0, 0, fa[0], fb[0]);
+  read_frag(0, 1, fa[1], fb[1]);
+#endif
+  if constexpr (A_MC || B_MC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // main loop: one straight-line block per K tile (past-the-end tiles load zeros for free, see load_a).
-  // The four K-chunks of the tile are separated by the staging work for the following tiles so that each
-  // short burst of ds_write / buffer_load issues in the shadow of a 64-cycle MFMA; sched_barrier(0x6) pins the
-  // memory ops and MFMAs in this order while letting the address arithmetic (VALU/SALU) float between MFMAs.
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    read_frag(cur, 0, fa[0], fb[0]);
-    read_frag(cur, 1, fa[1], fb[1]);
-    SO_SB();
-    mma(fa[0], fb[0]);
-    SO_SB();
-    store_a(cur ^ 1, ra);   // tile kt+1, loaded during the previous iteration
-    read_frag(cur, 2, fa[0], fb[0]);
-    SO_SB();
-    mma(fa[1], fb[1]);
-    SO_SB();
-    store_b(cur ^ 1, rb);
-    read_frag(cur, 3, fa[1], fb[1]);
-    SO_SB();
-    mma(fa[0], fb[0]);
-    SO_SB();
-    load_a(kt + 2, ra);     // lands while tile kt+1 is multiplied
-    SO_SB();
-    mma(fa[1], fb[1]);
-    SO_SB();
-    load_b(kt + 2, rb);
-    __syncthreads();
-    cur ^= 1;
+  // one K tile: multiply LDS[CUR]; stage registers (sa, sb) -> LDS[CUR ^ 1]; refill them with tile `kt_load`.  Each burst of
+  // ds_write / buffer_load issues in the shadow of a 4-MFMA group; sched_barrier(0x6) pins memory ops and MFMAs in this
+  // order while the address arithmetic (VALU / SALU) floats.
+  // sched_barrier(0) in front of each staging burst: the register shuffles of the transposed stores (v_mov into adjacent
+  // pairs for ds_write_b64 / b128) are VALU and would otherwise float to the top of the tile - dragging the s_waitcnt vmcnt
+  // of the loads they read with them (seen in the ISA: vmcnt(1) before the first MFMA of every tile).
+#define SO_KTILE(CUR, sa, sb, kt_load)      \
+  do {                                      \
+    SO_READ_FRAG(CUR, 0, fa[0], fb[0]);     \
+    SO_READ_FRAG(CUR, 1, fa[1], fb[1]);     \
+    SO_SB();                                \
+    SO_MMA(fa[0], fb[0]);                   \
+    __builtin_amdgcn_sched_barrier(0);      \
+    SO_STORE_A((CUR) ^ 1, sa);              \
+    SO_LOAD_A(kt_load, sa);                 \
+    SO_READ_FRAG(CUR, 2, fa[0], fb[0]);     \
+    SO_SB();                                \
+    SO_MMA(fa[1], fb[1]);                   \
+    __builtin_amdgcn_sched_barrier(0);      \
+    SO_STORE_B((CUR) ^ 1, sb);              \
+    SO_LOAD_B(kt_load, sb);                 \
+    SO_READ_FRAG(CUR, 3, fa[1], fb[1]);     \
+    SO_SB();                                \
+    SO_MMA(fa[0], fb[0]);                   \
+    SO_SB();                                \
+    SO_MMA(fa[1], fb[1]);                   \
+    SO_SB();                                \
+    SO_SYNC();                              \
+  } while (0)
+  // the last tile of an odd trip count: nothing left to stage
+#define SO_KTILE_LAST(CUR)                  \
+  do {                                      \
+    SO_READ_FRAG(CUR, 0, fa[0], fb[0]);     \
+    SO_READ_FRAG(CUR, 1, fa[1], fb[1]);     \
+    SO_SB();                                \
+    SO_MMA(fa[0], fb[0]);                   \
+    SO_SB();                                \
+    SO_READ_FRAG(CUR, 2, fa[0], fb[0]);     \
+    SO_SB();                                \
+    SO_MMA(fa[1], fb[1]);                   \
+    SO_SB();                                \
+    SO_READ_FRAG(CUR, 3, fa[1], fb[1]);     \
+    SO_SB();                                \
+    SO_MMA(fa[0], fb[0]);                   \
+    SO_SB();                                \
+    SO_MMA(fa[1], fb[1]);                   \
+  } while (0)
+
+  if constexpr (TWO_STAGE) {
+    // (no break out of the middle of the body: a second exit makes the register stages live across a merge point and the
+    //  compiler rotates them with v_mov copies behind a vmcnt(0))
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {
+      SO_KTILE(0, ra, rb, kt + 3);
+      SO_KTILE(1, ra1, rb1, kt + 4);
+    }
+    if (kt < kt_end) {
+      SO_KTILE_LAST(0);
+      __syncthreads();   // the epilogue reuses the LDS stages as its transposition patches
+    }
+  } else {
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      SO_KTILE(cur, ra, rb, kt + 2);
+      cur ^= 1;
+    }
   }
 
   // ---------------- epilogue ----------------

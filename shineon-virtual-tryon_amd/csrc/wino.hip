@@ -261,6 +261,10 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
     const int id = tid + WF_NT * m;
     a_src[m] = -1;
     a_dst[m] = -1;
+    if (id >= 360) {   // no second quad for this thread: it repeats its first one (same load, same store - idempotent and
+      a_src[m] = a_src[0];   // branch-free, where an `if` around the second ds_write split the K step into basic blocks)
+      a_dst[m] = a_dst[0];
+    }
     if (id < 360) {
       const int pix = id >> 1;
       const int ppy = pix / 18, ppx = pix - ppy * 18;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
   };
   auto store_a = [&](int st, const f32x4 (&v)[2]) {
     *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[0]) = v[0];
-    if (a_dst[1] >= 0) *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[1]) = v[1];
+    *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[1]) = v[1];
   };
   auto store_b = [&](int st, const f32x4 (&v)[WF_BQ]) {
     float* dst = Bs + st * WF_BSTAGE + b_dst0;
@@ -334,10 +338,16 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
 #ifndef WF_RING
 #define WF_RING 1
 #endif
-  auto kstep = [&](int rd, f32x4 (&ra)[2], f32x4 (&rb)[WF_BQ], int s_next) {
+#ifndef WF_ABLATE
+#define WF_ABLATE 0
+#endif
+  // WF_ABLATE (measurement builds only, results WRONG): 1 no MFMAs, 2 no LDS stores, 4 no global loads, 8 no barrier,
+  // 16 fragments (LDS reads + input transform) built once instead of every step, 32 LDS reads kept but no transform VALU
+  f32x4 v[4], bf[NKG][4];
+  auto build_frags = [&](int rd) {
     const float* as = As + rd * WF_ASTAGE;
     const float* bs = Bs + rd * WF_BSTAGE;
-    f32x4 d1[4], d2[4], bf[NKG][4];
+    f32x4 d1[4], d2[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       d1[b] = *reinterpret_cast<const f32x4*>(as + fa1_0 + ((b >> 1) + (b & 1) * 9) * WF_APIX);
@@ -348,35 +358,62 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
 #pragma unroll
       for (int j = 0; j < 4; ++j) bf[g][j] = *reinterpret_cast<const f32x4*>(bs + fb_0 + (j * WF_KB + g * 32) * 8);
     WF_SB();
-    f32x4 t[4], v[4];
+#if WF_ABLATE & 32
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = d1[j] + d2[j];
+#else
+    f32x4 t[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[b][e] = __builtin_fmaf(sgn, d2[b][e], d1[b][e]);
-    v[0] = t[0] - t[2];
-    v[1] = t[1] + t[2];
-    v[2] = t[2] - t[1];
-    v[3] = t[1] - t[3];
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int g = 0; g < NKG; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[g][j][e], acc[g][j], 0, 0, 0);
+    for (int e = 0; e < 4; ++e) {
+      v[0][e] = t[0][e] - t[2][e];
+      v[1][e] = t[1][e] + t[2][e];
+      v[2][e] = t[2][e] - t[1][e];
+      v[3][e] = t[1][e] - t[3][e];
+    }
+#endif
+  };
+#if WF_ABLATE & 1
+#define WF_MMA(e_)                                                                                 \
+  _Pragma("unroll") for (int g = 0; g < NKG; ++g) _Pragma("unroll") for (int j = 0; j < 4; ++j)   \
+      acc[g][j][0] += v[j][e_] * bf[g][j][e_];
+#else
+#define WF_MMA(e_)                                                                                 \
+  _Pragma("unroll") for (int g = 0; g < NKG; ++g) _Pragma("unroll") for (int j = 0; j < 4; ++j)   \
+      acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e_], bf[g][j][e_], acc[g][j], 0, 0, 0);
+#endif
+  auto kstep = [&](int rd, f32x4 (&ra)[2], f32x4 (&rb)[WF_BQ], int s_next) {
+#if !(WF_ABLATE & 16)
+    build_frags(rd);
+#endif
+    WF_MMA(0)
+    WF_MMA(1)
     WF_SB();
+#if WF_ABLATE & 2
+    asm volatile("" :: "v"(ra[0][0]), "v"(ra[1][3]), "v"(rb[0][0]), "v"(rb[WF_BQ - 1][3]));
+#else
     store_a(rd ^ 1, ra);     // the stage consumed by the NEXT step
     store_b(rd ^ 1, rb);
+#endif
     WF_SB();
-#pragma unroll
-    for (int e = 2; e < 4; ++e)
-#pragma unroll
-      for (int g = 0; g < NKG; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bf[g][j][e], acc[g][j], 0, 0, 0);
+    WF_MMA(2)
     WF_SB();
+    // Round 5: the refill is issued HERE, right behind the stores that vacated the registers (it used to be the last thing
+    // of the step): a load now has a quarter of this step + the fragment phase and first half of the next step to land
+    // (12+ MFMAs) instead of 8 MFMAs; the ISA had vmcnt(5) .. vmcnt(0) in front of the six ds_writes of every step.
+#if !(WF_ABLATE & 4)
     load_a(s_next, ra);
     load_b(s_next, rb);
+#endif
+    WF_SB();
+    WF_MMA(3)
+    WF_SB();
+#if !(WF_ABLATE & 8)
     __syncthreads();
+#endif
   };
 #if WF_RING == 2
   f32x4 ra0[2], ra1[2], rb0[WF_BQ], rb1[WF_BQ];
@@ -408,6 +445,9 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
     store_b(0, b0);
   }
   __syncthreads();
+#if WF_ABLATE & 16
+  build_frags(0);
+#endif
   int cur = 0;
   for (int s = 0; s < p.nks; ++s) {
     kstep(cur, ra0, rb0, s + 2);

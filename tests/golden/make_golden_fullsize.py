@@ -5,8 +5,15 @@ oracle at full size (~700 s of the 1200 s GPU run was this, 
     python tests/golden/make_golden_fullsize.py            # every case (about 1.5 h on 8 cores, <= 45 GiB)
     python tests/golden/make_golden_fullsize.py chain_bs4 c5 ...
 
-The oracle is pinned to the imported reference by tests/golden/make_golden.py / tests/test_oracle_golden.py; this script
-imports nothing from /root/reference.  Cases and their inputs: tests/fullsize_cases.py; format: tests/gradfix.py.
+The oracle is pinned to the imported reference by tests/golden/make_golden.py / tests/test_oracle_golden.py.  Cases and their
+inputs: tests/fullsize_cases.py; format: tests/gradfix.py.
+
+Round 5: where /root/reference is present (the build container) the FP32 leg of the try-on / warp cases is the REFERENCE's
+own evaluation - `models.warp_model.WarpModel` / `models.unet_mask_model.UnetMaskModel` imported through make_golden.py's
+shim (torchvision / pytorch_lightning / tensorboard / flownet2 stand-ins), `training_step` + `backward` on the same procedural
+weights and inputs - and the fixture says so (`fp32_source` = "reference").  The fp64 leg and the kink bracket stay the
+oracle's (the reference has no fp64 mode worth trusting: its hard-coded `.float()` casts are few, but the oracle is the
+audited restatement).  SHINEON_GOLDEN_FP32=oracle forces the round-4 behaviour (oracle in fp32).
 """
 import os
 import sys
@@ -28,6 +35,67 @@ import gradfix as gf  # noqa: E402
 import sams_helpers as sh  # noqa: E402
 from oracle import sams_oracle as so  # noqa: E402
 from oracle import shineon_oracle as oracle  # noqa: E402
+
+
+REF = "/root/reference"
+USE_REFERENCE = os.path.isdir(REF) and os.environ.get("SHINEON_GOLDEN_FP32", "reference") == "reference"
+_SHIM = [False]
+
+
+def _reference():
+    """Import hook for the reference's modules (build container only)."""
+    if not _SHIM[0]:
+        sys.path.insert(0, HERE)
+        import make_golden as mg   # the shim lives there; importing it has no side effects besides sys.path
+
+        mg.install_shim()
+        _SHIM[0] = mg
+    return _SHIM[0]
+
+
+def reference_warp(sd, batch):
+    """models/warp_model.py:74-98 on the reference's own WarpModel: (gradients by state_dict key, outputs, BatchNorm updates)."""
+    mg = _reference()
+    from models.warp_model import WarpModel
+
+    hp = mg.hp_namespace(person_inputs=fc.WHP["person_inputs"], cloth_inputs=fc.WHP["cloth_inputs"])
+
+    def fresh():
+        m = WarpModel(hp)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+        return m.train()
+
+    model = fresh()
+    res = model.training_step(dict(batch), 0)
+    res.minimize.backward()
+    with torch.no_grad():   # grid / theta of the same training-mode forward, from a twin (training_step does not keep them)
+        grid, theta = fresh()(torch.cat([batch[k] for k in hp.person_inputs], 1), torch.cat([batch[k] for k in hp.cloth_inputs], 1))
+    msd = model.state_dict()
+    bn = {k: msd[k].detach().clone() for k in msd if k.endswith(("running_mean", "running_var"))}
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref = {"theta": theta, "grid": grid, "warped_cloth": model.warped_cloth.detach(), "loss/G": res.minimize.detach()}
+    return grads, ref, bn
+
+
+def reference_unet(sd, batch, hp):
+    """models/unet_mask_model.py:137-217 on the reference's own UnetMaskModel (the VGG19 of the loss holds `sd`'s weights)."""
+    mg = _reference()
+    from models.unet_mask_model import UnetMaskModel
+
+    ns = mg.hp_namespace(**{k: v for k, v in hp.items()})
+    model = UnetMaskModel(ns)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    res = model.training_step(dict(batch), 0)
+    res.minimize.backward()
+    cat = lambda ts: None if ts is None or ts[0] is None else torch.cat([t.detach() for t in ts], 1)  # noqa: E731
+    ref = {"p_rendereds": cat(model.p_rendereds), "tryon_masks": cat(model.tryon_masks), "p_tryons": cat(model.p_tryons),
+           "flow_masks": cat(model.flow_masks) if getattr(model, "flow_masks", None) is not None else None}
+    for k in fc.UNET_LOG_KEYS:
+        ref[k] = res.logs[k].detach() if k in res.logs else torch.zeros(())
+    grads = {"unet." + k: p.grad.detach().clone() for k, p in model.unet.named_parameters() if p.grad is not None}
+    ref["_model"] = model
+    return grads, ref
 
 
 def _params(sd, trainable, dtype):
@@ -61,7 +129,7 @@ def oracle_unet(sd, batch, hp, dtype=torch.float32):
 def kink_spread(run64, exact):
     spread = {}
     for sign in (1.0, -1.0):
-        with sh.kink_shift(sign * 1e-5):
+        with sh.kink_shift(sign * sh.KINK_DELTA):
             shifted = run64()
         for k, v in shifted.items():
             if k in exact:
@@ -74,9 +142,15 @@ def gen_warp(bs, out=None, prefix=""):
     batch = fc.smooth_batch(bs)
     _, sd = fc.build_warp()
     bn = {}
-    p32, r32 = oracle_warp(sd, batch, bn_updates=bn)
+    if USE_REFERENCE:
+        g32, r32, bn = reference_warp(sd, batch)
+    else:
+        p32, r32 = oracle_warp(sd, batch, bn_updates=bn)
+        g32 = _grads(p32)
+    out[prefix + "fp32_source"] = np.array("reference" if USE_REFERENCE else "oracle")
     p64, r64 = oracle_warp(sd, batch, torch.float64)
-    g32, g64 = _grads(p32), _grads(p64)
+    g64 = _grads(p64)
+    assert set(g32) == set(g64), set(g32) ^ set(g64)
     kink = kink_spread(lambda: _grads(oracle_warp(sd, batch, torch.float64)[0]), g64)
     out[prefix + "digest:weights"] = gf.input_digest(sd)
     out[prefix + "digest:batch"] = gf.input_digest(batch)
@@ -95,9 +169,15 @@ def gen_warp(bs, out=None, prefix=""):
 
 def gen_unet(batch, sd, hp, out=None, prefix="", kinks=True):
     out = {} if out is None else out
-    p32, r32 = oracle_unet(sd, batch, hp)
+    if USE_REFERENCE:
+        g32, r32 = reference_unet(sd, batch, hp)
+    else:
+        p32, r32 = oracle_unet(sd, batch, hp)
+        g32 = _grads(p32)
+    out[prefix + "fp32_source"] = np.array("reference" if USE_REFERENCE else "oracle")
     p64, r64 = oracle_unet(sd, batch, hp, torch.float64)
-    g32, g64 = _grads(p32), _grads(p64)
+    g64 = _grads(p64)
+    assert set(g32) == set(g64), set(g32) ^ set(g64)
     # GELU U-Net: the only kinks are the VGG's ReLUs / max-pools (frozen weights; they shape dL/dp_tryon) and L1's sign
     kink = kink_spread(lambda: _grads(oracle_unet(sd, batch, hp, torch.float64)[0]), g64) if kinks else None
     out[prefix + "digest:weights"] = gf.input_digest(sd)
@@ -139,6 +219,43 @@ def case_c5():
     _, sd = fc.build_c5()
     batch = fc.flatten_frames(fc.smooth_batch(1, n_frames=5))
     return gen_unet(batch, sd, fc.C5HP)
+
+
+def case_c5_bs2():
+    """BASELINE config 5 at the batch bench.py times it at (bs = 2 sequences of 5 frames): other GEMM M extents, other
+    committed plans / tiles / split-K orders than the bs = 1 case, and the step goes through the graph-replayed TrainStep."""
+    _, sd = fc.build_c5()
+    batch = fc.flatten_frames(fc.smooth_batch(2, n_frames=5))
+    return gen_unet(batch, sd, fc.C5HP)
+
+
+def case_c3_bench_inputs():
+    """Forward only, on the inputs bench.py TIMES: synthetic_batch(4, seed=420, smooth=False) - U(-1, 1) white-noise images
+    (SURVEY 8d / BASELINE.md 3), not the band-limited images of the gradient cases.  UnetMaskModel outputs, the five logged
+    scalars and the five VGG19 taps of p_tryon from the reference's own modules; fp64 from the oracle."""
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+
+    assert USE_REFERENCE, "this case records the reference's own forward: run it in the build container"
+    batch = synthetic_batch(4, "cpu", seed=420, smooth=False)
+    _, sd = fc.build_unet()
+    out = {"digest:weights": gf.input_digest(sd), "digest:batch": gf.input_digest(batch), "fp32_source": np.array("reference")}
+    with torch.no_grad():
+        r64 = oracle.unet_mask_losses(_params(sd, lambda k: False, torch.float64), _cast(batch, torch.float64), fc.UHP)
+    _, r32 = reference_unet(sd, batch, fc.UHP)   # (its backward pass is simply not recorded)
+    for name in ("p_rendereds", "tryon_masks", "p_tryons"):
+        # p_tryon (what the loss sees) and the mask as FULL tensors: no sampling argument; p_rendered on a 1/4 lattice
+        gf.pack_output(out, name, r32[name], r64[name], stride=2 if name == "p_rendereds" else 1)
+    for k in fc.UNET_LOG_KEYS:
+        out["log32:" + k] = np.float64(float(r32[k]))
+        out["log64:" + k] = np.float64(float(r64[k]))
+    model = r32["_model"]
+    with torch.no_grad():
+        taps32 = model.criterionVGG.vgg(r32["p_tryons"])
+        x64 = r64["p_tryons"]
+        taps64 = oracle.vgg19_features({k: v.double() for k, v in sd.items() if v.is_floating_point()}, x64)
+    for i, (a, b) in enumerate(zip(taps32, taps64)):
+        gf.pack_output(out, f"vgg_tap{i + 1}", a, b, stride=(8, 8, 4, 4, 2)[i])
+    return out
 
 
 # ---- SAMS --------------------------------------------------------------------------------------------
@@ -247,7 +364,7 @@ def case_sams_full_generator_bs4():
     o64, g64 = run(torch.float64)
     spread = {}
     for sign in (1.0, -1.0):  # as the r03 test: the bracket from two more FP32 passes at this size
-        with sh.kink_shift(sign * 1e-5):
+        with sh.kink_shift(sign * sh.KINK_DELTA):
             _, g = run(torch.float32)
         for k, v in g.items():
             spread[k] = max(spread.get(k, 0.0), (v - g32[k]).abs().max().item())
@@ -261,7 +378,7 @@ def case_sams_full_generator_bs4():
 
 CASES = {
     "warp_bs2": case_warp_bs2, "chain_bs4": case_chain_bs4, "chain_bs8": case_chain_bs8,
-    "c5": case_c5, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
+    "c5": case_c5, "c5_bs2": case_c5_bs2, "c3_bench_inputs": case_c3_bench_inputs, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
     "sams_progressive": case_sams_progressive, "sams_full_generator_bs4": case_sams_full_generator_bs4,
     "sams_full_three_steps": case_sams_full_three_steps,
 }

@@ -196,3 +196,63 @@ def test_c5_full_size_five_frames_flow_warp_vs_oracle(cuda):
         r = float(fix["log32:" + k])
         assert abs(float(res.logs[k]) - r) <= 2e-5 + 3e-5 * abs(r), (k, float(res.logs[k]), r)
     gf.compare_grads(_grads(model, "unet."), gf.GradFixture(fix, "grad:"), "C5 n_frames=5 flow_warp ngf=167", rule="tryon")
+
+
+def test_c5_at_the_timed_batch_through_the_graph_replayed_train_step(cuda):
+    """BASELINE config 5 as bench.py --config c5 times it: bs = 2 sequences of 5 frames through trainer.TrainStep with the step
+    captured as a hipGraph and REPLAYED (other GEMM M extents than the bs = 1 case above, hence other committed plans, tiles
+    and split-K orders).  Outputs, the five losses and every gradient of the replayed step against the committed values (fp32
+    leg: the reference's own UnetMaskModel, fp64 leg: the oracle).  No optimizer update is applied before the comparison:
+    TrainStep's exchange / Adam run after the graph, the gradients are read in between."""
+    from shineon_virtual_tryon_amd import trainer
+
+    fix = gf.load("c5_bs2")
+    model, sd = fc.build_c5(cuda)
+    gf.check_digest(fix, "digest:weights", sd)
+    batch_cpu = fc.smooth_batch(2, n_frames=5)
+    gf.check_digest(fix, "digest:batch", fc.flatten_frames(batch_cpu))
+    batch = fc.to_device(batch_cpu, cuda)
+    model.global_step = 1
+    (opt,), _ = model.configure_optimizers()
+    eng = trainer.TrainStep(model, opt, batch, graph=True, overlap=True)
+    assert eng._graphed is not None, "the step was not captured"
+    res = eng._graphed(batch)        # one REPLAY of the captured forward + backward (no exchange, no Adam yet)
+    torch.cuda.synchronize()
+    cat = lambda ts: torch.cat([t.contiguous() for t in ts], 1)  # noqa: E731
+    what = "C5 bs=2 (graph replay)"
+    for name, ours in (("p_rendereds", cat(model.p_rendereds)), ("tryon_masks", cat(model.tryon_masks)),
+                       ("flow_masks", cat(model.flow_masks)), ("p_tryons", cat(model.p_tryons))):
+        gf.check_output(fix, name, ours, 1e-4, what, either=True)
+    for k in fc.UNET_LOG_KEYS:
+        r = float(fix["log32:" + k])
+        assert abs(float(res.logs[k]) - r) <= 2e-5 + 3e-5 * abs(r), (k, float(res.logs[k]), r)
+    gf.compare_grads(_grads(model, "unet."), gf.GradFixture(fix, "grad:"), what, rule="tryon")
+
+
+def test_unet_forward_on_the_inputs_bench_py_times(cuda):
+    """The benchmark's OWN inputs: synthetic_batch(4, seed=420, smooth=False) - U(-1, 1) white-noise images, not the
+    band-limited images the gradient cases need (those keep grid_sample's tap flips out of the gradients; a forward pass has
+    no such excuse).  UnetMaskModel forward + the five logged scalars + the five VGG19 taps of p_tryon against the REFERENCE's
+    own modules (tests/golden/make_golden_fullsize.py c3_bench_inputs, imported through the shim): fp32 atol 1e-4 on the FULL
+    p_tryon / mask tensors (north_star's statement), p_rendered on a 1/4 lattice, taps on lattices relative to their maximum."""
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+
+    fix = gf.load("c3_bench_inputs")
+    assert str(fix["fp32_source"]) == "reference"
+    model, sd = fc.build_unet(cuda)
+    gf.check_digest(fix, "digest:weights", sd)
+    batch_cpu = synthetic_batch(4, "cpu", seed=420, smooth=False)
+    gf.check_digest(fix, "digest:batch", batch_cpu)
+    with torch.no_grad():
+        res = model.training_step(fc.to_device(batch_cpu, cuda), 0)
+        taps = model.criterionVGG.vgg(model.p_tryons[0])
+    what = "UnetMaskModel forward, bench inputs"
+    assert int(fix["p_tryons:stride"]) == 1 and int(fix["tryon_masks:stride"]) == 1
+    for name, ours in (("p_rendereds", model.p_rendereds[0]), ("tryon_masks", model.tryon_masks[0]), ("p_tryons", model.p_tryons[0])):
+        gf.check_output(fix, name, ours, 1e-4, what, mode="fp32")
+    for k in fc.UNET_LOG_KEYS:
+        if k in res.logs:
+            r = float(fix["log32:" + k])
+            assert abs(float(res.logs[k]) - r) <= 2e-5 + 2e-5 * abs(r), (what, k, float(res.logs[k]), r)
+    for i, t in enumerate(taps):
+        gf.check_output(fix, f"vgg_tap{i + 1}", t, 1e-4, what, rel_to_max=True, mode="either")
