@@ -112,8 +112,11 @@ long long so_wino_fused_weight_floats(int Ko, int C, int flip_transpose);
 int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream);
 int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream);
-/* 1 (default) = 32 output channels per block, three blocks per CU; 0 = 64 per block for Ko >= 64 (two per CU) */
+/* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
+ * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
+/* 1 (default): the fused kernel's two LDS stages are filled by LDS-DMA (buffer_load ... lds); 0: through registers + ds_write */
+void so_wino_fused_dma(int on);
 
 /* torch.bmm replacement (sagan.py:44,50; warp.py:63):
  * C[b] = act(alpha[0] * opA(A[b]) opB(B[b]) + bias[n] + res[b]),  alpha/bias/res optional (NULL).

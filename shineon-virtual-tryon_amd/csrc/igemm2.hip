@@ -241,7 +241,14 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
   constexpr int NT = NW * 64;
   constexpr int LDK = 36;  // KC row pitch: 144 B -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots
-  constexpr int LDA = A_MC ? 32 : LDK, LDB = B_MC ? 32 : LDK;  // MC tiles: unpadded + swizzled (so_swz)
+  // DMA (round 5): when BOTH operands are k-contiguous in memory (fprop, dgrad on transposed weights, NT GEMMs) the LDS
+  // stages are filled by LDS-DMA (`buffer_load_dwordx4 ... lds`) - no staging registers, no ds_write.  One instruction
+  // writes 64 lanes x 16 bytes to one contiguous KB = 8 tile rows of 32 k, so such tiles use the unpadded, XOR-swizzled
+  // 32-float row of the MC tiles, with the swizzle applied on the SOURCE side: lane l fetches the k quad that belongs in
+  // physical quad l & 7 of its row.  Mixed KC x MC launches keep the register pipeline for both operands (hipcc drains
+  // every outstanding load at a barrier while an LDS-DMA is in flight, which would collapse the register prefetch).
+  constexpr bool DMA = !A_MC && !B_MC;
+  constexpr int LDA = (A_MC || DMA) ? 32 : LDK, LDB = (B_MC || DMA) ? 32 : LDK;  // MC / DMA tiles: unpadded + swizzled (so_swz)
   constexpr int A_STAGE = BM * LDA;
   constexpr int B_STAGE = BN * LDB;
   constexpr int WGN = NW / 2;                          // waves along N
@@ -302,8 +309,30 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   const float invHWo = 1.0f / (float)(p.Ho * p.Wo > 0 ? p.Ho * p.Wo : 1);
 
   // ---------------- per-thread loader state (K-tile invariant) -----------------
-  const int kq = tid & 7;      // KC: quad within the 32-wide k row
   const int krow8 = tid >> 3;  // KC: row within a 32-row pass
+  // KC: quad within the 32-wide k row.  DMA: the lane's PHYSICAL quad is tid & 7 (LDS-DMA is lane-linear); it holds logical
+  // quad (tid & 7) ^ so_swz(row) - the same for every pass j, since so_swz only looks at row bits 1..4 and passes are 32+ rows apart
+  const int kq = DMA ? ((tid & 7) ^ so_swz(krow8)) : (tid & 7);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // in an SGPR: LDS-DMA bases (M0) are wave-uniform
+  (void)wave_u;
+  typedef __attribute__((address_space(3))) void* so_lds_ptr;
+  // one staged quad: into the register stage, or straight into LDS stage `fill_st` (rows 8 * wave .. + 7 of pass j)
+#define SO_EMIT_A(j, off)                                                                                                        \
+  do {                                                                                                                           \
+    if constexpr (DMA)                                                                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (so_lds_ptr)(As + fill_st * A_STAGE + (8 * wave_u + RPP * (j)) * 32), 16,     \
+                                               (int)(off), 0, 0, 0);                                                             \
+    else                                                                                                                         \
+      dst[j] = so_bload(rA, (off));                                                                                              \
+  } while (0)
+#define SO_EMIT_B(j, off)                                                                                                        \
+  do {                                                                                                                           \
+    if constexpr (DMA)                                                                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (so_lds_ptr)(Bs + fill_st * B_STAGE + (8 * wave_u + RPP * (j)) * 32), 16,     \
+                                               (int)(off), 0, 0, 0);                                                             \
+    else                                                                                                                         \
+      dst[j] = so_bload(rB, (off));                                                                                              \
+  } while (0)
   // A operand, KC: element offset of the row's origin pixel and its (h0, w0); invalid rows get h0 = -2^28
   int a_org[AJ], a_h0[AJ], a_w0[AJ];
   (void)a_org; (void)a_h0; (void)a_w0;
@@ -441,7 +470,8 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 
   // Issue the (branch-free) global loads of K tile `kt` into ra/rb.  Tiles at or beyond kt_end read as zeros
   // without touching memory (every lane goes out of range), which lets the main loop run without tail branches.
-  auto load_a = [&](int kt, f32x4 (&dst)[AJ]) {
+  auto load_a = [&](int kt, f32x4 (&dst)[AJ], int fill_st) {
+    (void)fill_st;
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!A_MC) {
@@ -461,7 +491,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int hi = a_h0[j] + (int)r, wi = a_w0[j] + (int)s;
           const bool ok = kvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_A(j, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
         }
       } else if constexpr (MODE == MODE_DGRAD) {
         unsigned tapi, ko, tr, ts;
@@ -477,13 +507,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
         for (int j = 0; j < AJ; ++j) {
           const int ho = a_h0[j] - (int)tr, wo = a_w0[j] - (int)ts;
           const bool ok = kvalid & ((unsigned)ho < (unsigned)p.Ho) & ((unsigned)wo < (unsigned)p.Wo);
-          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_A(j, (((unsigned)(a_org[j] + tap_off) * 4u) | (ok ? 0u : SO_OOB)));
         }
       } else {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
           const bool ok = kvalid & (a_h0[j] == 0);
-          dst[j] = so_bload(rA, (((unsigned)(a_org[j] + (int)kk) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_A(j, (((unsigned)(a_org[j] + (int)kk) * 4u) | (ok ? 0u : SO_OOB)));
         }
       }
     } else {
@@ -493,11 +523,12 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       for (int j = 0; j < AJ; ++j) {
         const int kk = k0 + a_kr * AJ + j;
         const bool ok = colok & (kk < Klim);
-        dst[j] = so_bload(rA, (((unsigned)(kk * p.lda + col) * 4u) | (ok ? 0u : SO_OOB)));
+        SO_EMIT_A(j, (((unsigned)(kk * p.lda + col) * 4u) | (ok ? 0u : SO_OOB)));
       }
     }
   };
-  auto load_b = [&](int kt, f32x4 (&dst)[BJ]) {
+  auto load_b = [&](int kt, f32x4 (&dst)[BJ], int fill_st) {
+    (void)fill_st;
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!B_MC) {
@@ -518,7 +549,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
         const bool ok = kvalid & (b_row[j] >= 0);
-        dst[j] = so_bload(rB, (((unsigned)(b_row[j] + koff) * 4u) | (ok ? 0u : SO_OOB)));
+        SO_EMIT_B(j, (((unsigned)(b_row[j] + koff) * 4u) | (ok ? 0u : SO_OOB)));
       }
     } else {
       const int col = n0 + b_mq * 4;
@@ -532,13 +563,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
             const int r = d_r0 + p.stride * u_cur_r, s = d_s0 + p.stride * u_cur_s;
             const int ko = u_cur_c0 + b_kr * BJ + j;
             const bool ok = (kk < Klim) & (col < p.N);
-            dst[j] = so_bload(rB, (((unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
+            SO_EMIT_B(j, (((unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
             continue;
           }
           // in-place OHWI weights: k row kk = (class tap (tr, ts), ko), carried incrementally like the WGRAD pixel
           const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
-          dst[j] = so_bload(rB, (((unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_B(j, (((unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
           if (j + 1 < BJ) {
             dg_ko += 1;
             const bool c1 = dg_ko == p.Ko;
@@ -561,7 +592,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int hi = wg_ho * p.stride - p.pad + w_r;
           const int wi = wg_wo * p.stride - p.pad + w_s;
           const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-          dst[j] = so_bload(rB, (((unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_B(j, (((unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u) | (ok ? 0u : SO_OOB)));
           if (j + 1 < BJ) {  // next k row = next output pixel
             wg_wo += 1;
             const bool cw = wg_wo == p.Wo;
@@ -581,7 +612,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           }
         } else {
           const bool ok = (kk < Klim) & (col < p.N);
-          dst[j] = so_bload(rB, (((unsigned)(kk * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
+          SO_EMIT_B(j, (((unsigned)(kk * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
         }
       }
     }
@@ -639,13 +670,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * WTM + i * 32 + li;
-      const int off = A_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+      const int off = (A_MC || DMA) ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
       af[i] = *reinterpret_cast<const f32x4*>(as + off);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * WTN + j * 32 + li;
-      const int off = B_MC ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
+      const int off = (B_MC || DMA) ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
       bf[j] = *reinterpret_cast<const f32x4*>(bs + off);
     }
   };
@@ -694,8 +725,8 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #define SO_LOAD_A(kt, r)
 #define SO_LOAD_B(kt, r)
 #else
-#define SO_LOAD_A(kt, r) load_a(kt, r)
-#define SO_LOAD_B(kt, r) load_b(kt, r)
+#define SO_LOAD_A(kt, r) load_a(kt, r, 0)
+#define SO_LOAD_B(kt, r) load_b(kt, r, 0)
 #endif
 #if SO_ABLATE & 8
 #define SO_SYNC()
@@ -715,18 +746,21 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // buffers are addressed statically; the loaders still see the tiles in order (their incremental index state relies on it).
   // The 128x128 / 4-wave tile (four accumulators per wave, 160+ VGPRs) has no room for a second stage: it keeps ONE stage
   // with the same early issue point (behind the first / second MFMA group), i.e. one whole K tile of cover.
-  constexpr bool TWO_STAGE = NW == 4 && TM * TN <= 2;   // (8-wave tiles: two blocks per CU need <= 128 VGPRs)
+  constexpr bool TWO_STAGE = !DMA && NW == 4 && TM * TN <= 2;   // (8-wave tiles: two blocks per CU need <= 128 VGPRs)
   f32x4 ra1[TWO_STAGE ? AJ : 1], rb1[TWO_STAGE ? BJ : 1];
   (void)ra1; (void)rb1;
-  {
+  if constexpr (DMA) {
+    load_a(kt_begin, ra, 0);    // (ra / rb are unused in this mode: the quads go straight into LDS stage 0)
+    load_b(kt_begin, rb, 0);
+  } else {
     f32x4 ra0[AJ], rb0[BJ];
-    load_a(kt_begin, ra0);
-    load_b(kt_begin, rb0);
-    load_a(kt_begin + 1, ra);
-    load_b(kt_begin + 1, rb);
+    load_a(kt_begin, ra0, 0);
+    load_b(kt_begin, rb0, 0);
+    load_a(kt_begin + 1, ra, 0);
+    load_b(kt_begin + 1, rb, 0);
     if constexpr (TWO_STAGE) {
-      load_a(kt_begin + 2, ra1);
-      load_b(kt_begin + 2, rb1);
+      load_a(kt_begin + 2, ra1, 0);
+      load_b(kt_begin + 2, rb1, 0);
     }
     store_a(0, ra0);
     store_b(0, rb0);
@@ -786,7 +820,50 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     SO_MMA(fa[1], fb[1]);                   \
   } while (0)
 
-  if constexpr (TWO_STAGE) {
+  // LDS-DMA form: the fill of tile t+1 is issued at the top of tile t into the stage all waves left at the barrier that ended
+  // tile t-1, and is drained by the vmcnt(0) hipcc puts in front of the barrier that ends tile t: one whole tile to land.
+  // sched_barrier(0) around that barrier keeps the MFMAs (which touch no memory) from sinking below it.
+#define SO_KTILE_DMA(CUR, kt_next)                                  \
+  do {                                                              \
+    if ((kt_next) < kt_end) {                                       \
+      SO_LOAD_A_DMA(kt_next, (CUR) ^ 1);                            \
+      SO_LOAD_B_DMA(kt_next, (CUR) ^ 1);                            \
+    }                                                               \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    SO_READ_FRAG(CUR, 0, fa[0], fb[0]);                             \
+    SO_READ_FRAG(CUR, 1, fa[1], fb[1]);                             \
+    SO_SB();                                                        \
+    SO_MMA(fa[0], fb[0]);                                           \
+    SO_SB();                                                        \
+    SO_READ_FRAG(CUR, 2, fa[0], fb[0]);                             \
+    SO_SB();                                                        \
+    SO_MMA(fa[1], fb[1]);                                           \
+    SO_SB();                                                        \
+    SO_READ_FRAG(CUR, 3, fa[1], fb[1]);                             \
+    SO_SB();                                                        \
+    SO_MMA(fa[0], fb[0]);                                           \
+    SO_SB();                                                        \
+    SO_MMA(fa[1], fb[1]);                                           \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    SO_SYNC();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#if SO_ABLATE & 4
+#define SO_LOAD_A_DMA(kt, st)
+#define SO_LOAD_B_DMA(kt, st)
+#else
+#define SO_LOAD_A_DMA(kt, st) load_a(kt, ra, st)
+#define SO_LOAD_B_DMA(kt, st) load_b(kt, rb, st)
+#endif
+
+  if constexpr (DMA) {
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {
+      SO_KTILE_DMA(0, kt + 1);
+      SO_KTILE_DMA(1, kt + 2);
+    }
+    if (kt < kt_end) SO_KTILE_DMA(0, kt + 1);
+  } else if constexpr (TWO_STAGE) {
     // (no break out of the middle of the body: a second exit makes the register stages live across a merge point and the
     //  compiler rotates them with v_mov copies behind a vmcnt(0))
     int kt = kt_begin;
@@ -1041,8 +1118,9 @@ void so_prof_end(int slot, hipStream_t stream) {
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
   SoIgemm p = p_in;
-  constexpr int A_STAGE = BM * (A_MC ? 32 : 36);
-  constexpr int B_STAGE = BN * (B_MC ? 32 : 36);
+  constexpr bool DMA = !A_MC && !B_MC;
+  constexpr int A_STAGE = BM * ((A_MC || DMA) ? 32 : 36);
+  constexpr int B_STAGE = BN * ((B_MC || DMA) ? 32 : 36);
   constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
   auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN, NW>;
   static bool attr_set = false;

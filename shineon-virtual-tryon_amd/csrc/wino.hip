@@ -224,15 +224,27 @@ constexpr int WF_ASTAGE = 10 * WF_AROW * WF_APIX;   // 1600 floats = 6.25 KB
 //   NKG = 1: 16 MFMAs per wave and K step, 44.5 KB LDS, <= 168 VGPRs, THREE blocks per CU;
 //   NKG = 2: the four A fragments of a lane's tile (8 LDS reads + 32 VALU of input transform) feed 32 MFMAs instead of 16,
 //            76.5 KB LDS, <= 256 VGPRs, TWO blocks per CU - for Ko >= 64.
-template <int NKG>
+// DMA = true (round 5, the default): both stages are filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers,
+// no ds_write instructions - the ablation builds (profiles/r05_wino_ablation.txt) put 25 % of the kernel's time on the
+// register round trip (ds_write_b128 issue + LDS store bandwidth 15 %, the loads' waits 10 %).  An LDS-DMA instruction writes
+// 64 lanes x 16 bytes to ONE contiguous KB of LDS (wave-uniform base in M0 + lane * 16), so the swizzles of both stages move
+// to the SOURCE side: lane l of a fill instruction fetches whatever quad belongs in slot l.  The A stage is rounded up to
+// 7 full instructions (448 quad slots, 400 used), image borders / padding / channel tails are out-of-range offsets (the
+// hardware writes zeros).  The fill of step s + 1 is issued at the top of step s - all waves have left the stage it
+// overwrites at the barrier that ended step s - 1 - and is drained by the vmcnt(0) of the barrier that ends step s: a whole
+// step (16 NKG MFMAs per wave) to land.
+constexpr int WF_ASTAGE_DMA = 448 * 4;
+template <int NKG, bool DMA>
 __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const WinoP p) {
   constexpr int WF_KB = 32 * NKG;
   constexpr int WF_BSTAGE = 16 * WF_KB * 8;
   constexpr int WF_BQ = 16 * WF_KB * 2 / WF_NT;       // B quads per thread per step (4 or 8)
+  constexpr int A_STAGE = DMA ? WF_ASTAGE_DMA : WF_ASTAGE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
-  float* Bs = smem + 2 * WF_ASTAGE;
-  const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+  float* Bs = smem + 2 * A_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, in an SGPR: per-wave choices become scalar branches
   const int li = lane & 31, lh = lane >> 5;
 
   // XCD-aware block -> (patch, ko block) map: XCD x works on the x-th contiguous eighth of the (patch, kb) order, so the
@@ -299,13 +311,72 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
     for (int m = 0; m < WF_BQ; ++m) dst[m] = wf_bload(rU, ok ? (unsigned)(base + m * b_src_m) * 4u : WF_OOB);
   };
   auto store_a = [&](int st, const f32x4 (&v)[2]) {
-    *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[0]) = v[0];
-    *reinterpret_cast<f32x4*>(As + st * WF_ASTAGE + a_dst[1]) = v[1];
+    *reinterpret_cast<f32x4*>(As + st * A_STAGE + a_dst[0]) = v[0];
+    *reinterpret_cast<f32x4*>(As + st * A_STAGE + a_dst[1]) = v[1];
   };
   auto store_b = [&](int st, const f32x4 (&v)[WF_BQ]) {
     float* dst = Bs + st * WF_BSTAGE + b_dst0;
 #pragma unroll
     for (int m = 0; m < WF_BQ; ++m) *reinterpret_cast<f32x4*>(dst + m * 128 * 8) = v[m];
+  };
+
+  // ---- LDS-DMA fill (DMA = true) --------------------------------------------------------------------------------------
+  // A: 7 instructions of 64 quad slots (slot = (row slot * 20 + column slot) * 2 + physical quad); wave w issues j = w and
+  // j = w + 4.  B: 16 NKG instructions of 1 KB (32 rows = 32 output channels of one transform point); wave w issues the
+  // 4 NKG instructions of its own transformed row (xi = 4 w + j) - any assignment would do, the barrier publishes all of them.
+  constexpr int NA_DMA = 2, NB_DMA = 4 * NKG;
+  int da_src[NA_DMA];      // element offset of the lane's quad at step 0, or -1 (border / padding slot / no instruction)
+  int da_q4[NA_DMA];       // first channel of that quad within the step's 8 channels (0 or 4)
+  int db_src[NB_DMA];      // element offset in U at step 0, or -1 (output channel beyond Ko)
+  (void)da_src; (void)da_q4; (void)db_src;
+  if constexpr (DMA) {
+#pragma unroll
+    for (int m = 0; m < NA_DMA; ++m) {
+      const int j = wi + 4 * m;                       // instruction index (block-uniform per wave)
+      const int slot = 64 * j + lane;                 // quad slot in the stage
+      da_src[m] = -1;
+      da_q4[m] = 0;
+      if (j < 7 && slot < 400) {
+        const int pq = slot & 1, ps = slot >> 1;      // physical quad, pixel slot
+        const int rs = ps / WF_AROW, cs = ps - rs * WF_AROW;
+        const int ppy = rs < 5 ? 2 * rs : 2 * (rs - 5) + 1;
+        const int ppx = cs < 9 ? 2 * cs : 2 * (cs - 9) + 1;
+        const int h = h_org + ppy, w = w_org + ppx;
+        const int q = pq ^ (rs & 1);                  // logical channel quad stored in this physical quad
+        da_q4[m] = q * 4;
+        if (cs < 18 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) da_src[m] = ((n * p.H + h) * p.W + w) * p.ldx + q * 4;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NB_DMA; ++m) {
+      const int row = (4 * wi * WF_KB) + 32 * m + (lane >> 1);     // row of the B stage = xi * KB + ko_local
+      const int xi = row / WF_KB, kol = row - xi * WF_KB;
+      const int q = (lane & 1) ^ ((row >> 3) & 1);                 // logical quad stored in this physical quad
+      db_src[m] = (k0 + kol < p.Ko) ? (xi * p.Ko + k0 + kol) * 8 + q * 4 : -1;
+    }
+  }
+  auto dma_fill = [&](int st, int s) {
+    if constexpr (DMA) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      float* as = As + st * A_STAGE;
+      float* bs = Bs + st * WF_BSTAGE;
+      const int c0 = 8 * s;
+#pragma unroll
+      for (int m = 0; m < NA_DMA; ++m) {
+        const int j = wi + 4 * m;
+        if (j < 7) {   // wave-uniform
+          const bool ok = (da_src[m] >= 0) & (c0 + da_q4[m] < p.C);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr)(as + 256 * j), 16, ok ? (unsigned)(da_src[m] + c0) * 4u : WF_OOB, 0, 0, 0);
+        }
+      }
+      const int ub = s * b_step;
+#pragma unroll
+      for (int m = 0; m < NB_DMA; ++m) {
+        const bool ok = db_src[m] >= 0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rU, (lds_ptr)(bs + (4 * wi * WF_KB + 32 * m) * 8), 16,
+                                                 ok ? (unsigned)(db_src[m] + ub) * 4u : WF_OOB, 0, 0, 0);
+      }
+    }
   };
 
   // ---- fragment addresses (K-step invariant) -------------------------------------------------------------------------
@@ -345,7 +416,7 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
   // 16 fragments (LDS reads + input transform) built once instead of every step, 32 LDS reads kept but no transform VALU
   f32x4 v[4], bf[NKG][4];
   auto build_frags = [&](int rd) {
-    const float* as = As + rd * WF_ASTAGE;
+    const float* as = As + rd * A_STAGE;
     const float* bs = Bs + rd * WF_BSTAGE;
     f32x4 d1[4], d2[4];
 #pragma unroll
@@ -415,6 +486,41 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
     __syncthreads();
 #endif
   };
+  if constexpr (DMA) {
+    // sched_barrier(0) on both sides of the closing barrier: MFMAs touch no memory, so without it the compiler sinks most of
+    // the step's MFMAs BELOW `s_waitcnt vmcnt(0); s_barrier` - i.e. drains the fill it has just issued (seen in the ISA)
+    auto kstep_dma = [&](int rd, int s_next) {
+#if !(WF_ABLATE & 4)
+      if (s_next < p.nks) dma_fill(rd ^ 1, s_next);   // block-uniform; the stage it overwrites was left at the last barrier
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#if !(WF_ABLATE & 16)
+      build_frags(rd);
+#endif
+      WF_MMA(0)
+      WF_MMA(1)
+      WF_SB();
+      WF_MMA(2)
+      WF_MMA(3)
+      __builtin_amdgcn_sched_barrier(0);
+#if !(WF_ABLATE & 8)
+      __syncthreads();   // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    dma_fill(0, 0);
+    __syncthreads();
+#if WF_ABLATE & 16
+    build_frags(0);
+#endif
+    // (no exit from the middle of the body: the accumulators would be live across a merge point and get copied)
+    int s = 0;
+    for (; s + 1 < p.nks; s += 2) {
+      kstep_dma(0, s + 1);
+      kstep_dma(1, s + 2);
+    }
+    if (s < p.nks) kstep_dma(0, s + 1);
+  } else {
 #if WF_RING == 2
   f32x4 ra0[2], ra1[2], rb0[WF_BQ], rb1[WF_BQ];
   {
@@ -454,6 +560,7 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
     cur ^= 1;
   }
 #endif
+  }
 
   // ---- epilogue: A^T M A -----------------------------------------------------------------------------------------------
   // columns (in registers): P[i][0] = M[i][0] + M[i][1] + M[i][2],  P[i][1] = M[i][1] - M[i][2] - M[i][3]
@@ -824,10 +931,15 @@ int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int f
 
 // y = gate(act(conv3x3_s1_p1(x) + bias)) in ONE launch; U from so_wino_fused_weights with (N, K) = (Ko, C) of THIS call
 // (for an input gradient call it with x = dy, C = the convolution's Ko, Ko = its C and the flip_transpose = 1 weights).
-// Output channels per block: 32 (three blocks per CU; the default - measured equal or better on every VGG layer and in the
-// step: 557-558 vs 551 frames/s) or 64 for Ko >= 64 (two blocks per CU, the A fragments feed 32 MFMAs instead of 16).
-static int g_wino_force_nkg1 = 1;
+// Output channels per block: 32 (three blocks per CU) or 64 for Ko >= 64 (two blocks per CU; the A fragments of a lane's
+// tile - 8 LDS reads + 32 VALU - feed 32 MFMAs instead of 16).  With LDS-DMA staging the 64-channel form wins wherever its grid
+// still covers the chip twice over (VGG conv1_2 / conv2_x on 8 images: 163 vs 169 us, 146 vs 155 us; equal on 4 images; it
+// loses on the small layers, 51 vs 48 us at 144 blocks - profiles/r05_wino_dma_ab.txt): chosen per launch from the grid size.
+// so_wino_fused_force_kb32: 1 = always 32, 0 = 64 whenever Ko >= 64, -1 (default) = that rule.
+static int g_wino_force_nkg1 = -1;
 void so_wino_fused_force_kb32(int on) { g_wino_force_nkg1 = on; }
+static int g_wino_dma = 1;
+void so_wino_fused_dma(int on) { g_wino_dma = on; }   // 1 (default): LDS-DMA staging; 0: the register-staged form (A/B measurements)
 // (A barrier-free variant - every wave staging only its own operands: B fragments straight from L2 into registers, its 8 of
 //  the 10 patch rows in a wave-private LDS region - was built and measured in round 3 (commit 3c3fa6b): correct, but 12 % SLOWER
 //  (conv1_2 176 vs 162 us, conv2_2 150 vs 131 us, step 576 vs 589 frames/s: 2x the patch loads, 5 instead of 1.4 loads per
@@ -846,20 +958,26 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   p.x_bytes = (unsigned)xb; p.u_bytes = (unsigned)ub;
   p.ldx = ldx; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.C = C; p.Ko = Ko; p.nbias = nbias;
   p.pbx = ((W + 1) / 2 + 7) / 8; p.pby = ((H + 1) / 2 + 3) / 4;
-  const int nkg = (Ko >= 64 && !g_wino_force_nkg1) ? 2 : 1;   // output channels per block: 64 (two groups per wave) or 32
+  int nkg = 1;   // output channels per block: 32, or 64 (two groups per wave)
+  if (Ko >= 64 && g_wino_force_nkg1 <= 0) {
+    const long long blocks64 = (long long)Nb * p.pbx * p.pby * ((Ko + 63) / 64);
+    if (g_wino_force_nkg1 == 0 || (g_wino_dma && blocks64 >= 1024)) nkg = 2;
+  }
   const int KB = 32 * nkg;
   p.nkb = (Ko + KB - 1) / KB; p.nks = (C + 7) / 8;
   p.act = act; p.act_param = act_param;
   const long long blocks = (long long)Nb * p.pbx * p.pby * p.nkb;
   if (blocks <= 0 || blocks > 0x7FFFFFFF) return SO_ERR_SHAPE;
-  const size_t lds = (size_t)(2 * (WF_ASTAGE + 16 * KB * 8)) * sizeof(float);
+  const bool dma = g_wino_dma != 0;
+  const size_t lds = (size_t)(2 * ((dma ? WF_ASTAGE_DMA : WF_ASTAGE) + 16 * KB * 8)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)((2 * (WF_ASTAGE + 16 * 32 * 8)) * sizeof(float)));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fused_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((2 * (WF_ASTAGE + 16 * 64 * 8)) * sizeof(float)));
+    hipError_t e = hipSuccess;
+    const void* kerns[4] = {reinterpret_cast<const void*>(wino_fused_k<1, false>), reinterpret_cast<const void*>(wino_fused_k<2, false>),
+                            reinterpret_cast<const void*>(wino_fused_k<1, true>), reinterpret_cast<const void*>(wino_fused_k<2, true>)};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+      e = hipFuncSetAttribute(kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2 * ((i >= 2 ? WF_ASTAGE_DMA : WF_ASTAGE) + 16 * 32 * (1 + (i & 1)) * 8)) * sizeof(float)));
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -870,10 +988,14 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
                                  (hipStream_t)stream);
   // algorithmic bytes: x and y once + the 16 Winograd-domain filter planes this kernel reads (16 / 9 of the 3x3 filter)
   so_prof_bytes(slot, 4.0 * ((double)Nb * H * W * ((double)C + (double)Ko) + 16.0 * (double)C * (double)Ko));
-  if (nkg == 2)
-    hipLaunchKernelGGL(wino_fused_k<2>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  if (nkg == 2 && dma)
+    hipLaunchKernelGGL((wino_fused_k<2, true>), dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  else if (nkg == 2)
+    hipLaunchKernelGGL((wino_fused_k<2, false>), dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+  else if (dma)
+    hipLaunchKernelGGL((wino_fused_k<1, true>), dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(wino_fused_k<1>, dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((wino_fused_k<1, false>), dim3((unsigned)blocks), dim3(WF_NT), lds, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);
   return SO_LAUNCH_CHECK();
 }

@@ -15,6 +15,8 @@ oracle runs on the GPU box at these sizes any more (r03: 700 s of the 1200 s dri
 
 Reference behaviour: models/warp_model.py:74-98, models/unet_mask_model.py:137-217.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -36,6 +38,8 @@ def no_layer_shape_is_measured_here(cuda, request):
     L = pkg.lib()
     before = L.so_igemm_plan_count()
     yield
+    if os.environ.get("SHINEON_PLANS_SAVE"):
+        return   # the plan-collection pass (tools/gpu_make_plans.sh): new shapes are measured on purpose and saved at exit
     if "unet_mask_model_bs4" in request.node.name:
         return   # the un-graphed model WITHOUT an optimizer: attention runs as separate q / k / v GEMMs (no flat gradient slab
                  # to write into), whose 31 shapes are not in the committed file; its route tally is reported, not pinned

@@ -19,6 +19,10 @@ def main():
     n, h, w, ci, co, k, s, p = (int(v) for v in sys.argv[2:10])
     reps = int(sys.argv[10]) if len(sys.argv) > 10 else 20
     L = pkg.lib()
+    if os.environ.get("WINO_DMA") is not None:      # fused Winograd kernel: LDS-DMA staging (1, default) or registers (0)
+        L.so_wino_fused_dma(int(os.environ["WINO_DMA"]))
+    if os.environ.get("WINO_KB32") is not None:     # 1 (default): 32 output channels per block; 0: 64 where Ko >= 64
+        L.so_wino_fused_force_kb32(int(os.environ["WINO_KB32"]))
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     ws = ops.workspace(dev)

@@ -79,7 +79,7 @@ def main():
             err_44 = float((y4 - y0).abs().max())
             L.so_wino_fused_force_kb32(0)   # the 64-output-channel / two-blocks-per-CU instantiation for comparison
             tf32 = timeit(fused)
-            L.so_wino_fused_force_kb32(1)
+            L.so_wino_fused_force_kb32(-1)
 
             err_d = err_w = float("nan")
             if nb * h * w <= 8 * 64 * 48:
