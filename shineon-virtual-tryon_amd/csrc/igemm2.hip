@@ -188,50 +188,11 @@ __device__ __forceinline__ f32x4 so_bload(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   return r;
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// MC staging: a thread holds J quads q[j] = operand[k0 + j][m4 .. m4+3] (memory is contiguous along m/n, so the
-// global loads stay 16-byte and coalesced along m) and leaves them K-CONTIGUOUS in LDS: row m4+i receives the J
-// values of k0 .. k0+J-1 in one ds_write (b128 / b64 / b32 for J = 4 / 2 / 1), so that the MFMA side reads every
-// operand with ds_read_b128.  Such tiles use an unpadded 32-float row whose eight 16-byte k-quads are XOR-swizzled
-// with so_swz(row): found by exhaustive search over bit-linear swizzles against the gfx950 bank/lane-group rules,
-// it makes the ds_read_b128 of a 32-row tile and the transposed b128 stores conflict-free (b64/b32: 2-way, free).
+// KC tiles ([rows][32 k], k-contiguous memory) use an unpadded 32-float row whose eight 16-byte k-quads are XOR-swizzled with
+// so_swz(row): found by exhaustive search over bit-linear swizzles against the gfx950 bank / lane-group rules, it makes the
+// ds_read_b128 of a 32-row tile conflict-free.
 __device__ __forceinline__ int so_swz(int row) {
   return ((row >> 2) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 1) ^ (row >> 4)) & 1) << 2);
-}
-
-// Two dwords from two UNRELATED registers to two consecutive LDS dwords in one instruction.  The transposed staging writes
-// (k, k+1) of one tile row, whose values sit in two different 16-byte load results: as a ds_write_b64 / b128 the pair has to
-// be assembled in adjacent registers first, and hipcc then rotates whole register stages with v_mov copies behind a
-// vmcnt(0) (seen in the ISA of every MC instantiation: it defeats the load pipeline).  ds_write2_b32 takes any two
-// registers and costs the same LDS issue time as ds_write_b64 (three source dwords).  The compiler does not count inline-asm
-// LDS operations: the K loop drains them with an explicit lgkmcnt(0) in front of its barrier (SO_SYNC).
-__device__ __forceinline__ void so_ds_write2(unsigned lds_addr, float a, float b) {
-  asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(lds_addr), "v"(a), "v"(b) : "memory");
-}
-__device__ __forceinline__ void so_ds_write2_hi(unsigned lds_addr, float a, float b) {
-  asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" : : "v"(lds_addr), "v"(a), "v"(b) : "memory");
-}
-__device__ __forceinline__ void so_ds_write1(unsigned lds_addr, float a) {
-  asm volatile("ds_write_b32 %0, %1" : : "v"(lds_addr), "v"(a) : "memory");
-}
-
-// `tile_addr`: LDS byte address of the stage (the low 32 bits of a __shared__ pointer are its LDS offset)
-template <int J>
-__device__ __forceinline__ void so_store_transposed(unsigned tile_addr, const int (&addr)[4], const f32x4 (&q)[J]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned d = tile_addr + (unsigned)addr[i] * 4u;
-    if constexpr (J == 4) {
-      so_ds_write2(d, q[0][i], q[1][i]);
-      so_ds_write2_hi(d, q[2][i], q[3][i]);
-    } else if constexpr (J == 2) {
-      so_ds_write2(d, q[0][i], q[1][i]);
-    } else {
-      static_assert(J == 1, "1, 2 or 4 quads per thread");
-      so_ds_write1(d, q[0][i]);
-    }
-  }
 }
 
 // NW = waves per block: 4 (2x2 wave grid) or 8 (2x4, BN = 128 only: twice the waves per SIMD for the same LDS
@@ -240,15 +201,20 @@ template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
   constexpr int NT = NW * 64;
-  constexpr int LDK = 36;  // KC row pitch: 144 B -> the 16 lanes of a ds_read_b128 group hit 16 distinct slots
-  // DMA (round 5): when BOTH operands are k-contiguous in memory (fprop, dgrad on transposed weights, NT GEMMs) the LDS
-  // stages are filled by LDS-DMA (`buffer_load_dwordx4 ... lds`) - no staging registers, no ds_write.  One instruction
-  // writes 64 lanes x 16 bytes to one contiguous KB = 8 tile rows of 32 k, so such tiles use the unpadded, XOR-swizzled
-  // 32-float row of the MC tiles, with the swizzle applied on the SOURCE side: lane l fetches the k quad that belongs in
-  // physical quad l & 7 of its row.  Mixed KC x MC launches keep the register pipeline for both operands (hipcc drains
-  // every outstanding load at a barrier while an LDS-DMA is in flight, which would collapse the register prefetch).
-  constexpr bool DMA = !A_MC && !B_MC;
-  constexpr int LDA = (A_MC || DMA) ? 32 : LDK, LDB = (B_MC || DMA) ? 32 : LDK;  // MC / DMA tiles: unpadded + swizzled (so_swz)
+  constexpr int LDK = 36;  // row pitch of the epilogue's wave-private transposition patches
+  // Staging (round 5): every LDS stage is filled by LDS-DMA (`buffer_load_dwordx4 ... lds`) - no staging registers, no
+  // ds_write.  One instruction writes 64 lanes x 16 bytes to one contiguous KB of LDS (wave-uniform base in M0 + lane * 16),
+  // i.e. the LDS image of a tile IS the order in which the lanes fetch it:
+  //   KC operand (k-contiguous memory): tile [rows][32 k]; an instruction = 8 rows x 128 B.  Rows are unpadded and their eight
+  //       k-quads XOR-swizzled with so_swz(row) on the SOURCE side (lane l fetches the quad that belongs in physical quad
+  //       l & 7 of its row); fragments = ds_read_b128 (4 consecutive k per lane half), conflict-free.
+  //   MC operand (memory contiguous along the GEMM row / column: both wgrad operands, in-place dgrad weights, NN / TN GEMMs):
+  //       tile [32 k][rows] exactly as it lies in memory - NO transposition; an instruction = 256 / rows k-rows.  A lane
+  //       reads its fragment as four ds_read_b32 (k, k+1, k+2, k+3 at its own row: 32 lanes = 32 consecutive dwords of one
+  //       k-row, conflict-free; the compiler pairs them into ds_read2_b32).  Rounds 1-4 transposed these operands in
+  //       registers (ds_write_b64 / b128 of assembled pairs; the ablation builds put 25 % of the weight-gradient kernels'
+  //       time on that path, profiles/r05_igemm_ablation.txt).
+  constexpr int LDA = 32, LDB = 32;   // KC row pitch (floats); MC tiles have row pitch BM / BN
   constexpr int A_STAGE = BM * LDA;
   constexpr int B_STAGE = BN * LDB;
   constexpr int WGN = NW / 2;                          // waves along N
@@ -258,6 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int RPP = NT / 8;                          // KC mode: tile rows covered per pass
   constexpr int AJ = BM / RPP, BJ = BN / RPP;          // 16-byte quads staged per thread per K tile
   constexpr int AQPR = BM / 4, BQPR = BN / 4;          // MC mode: quads per k-row
+  constexpr int APASS = BK / AJ, BPASS = BK / BJ;      // MC mode: k-rows covered by the block per pass j
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -310,29 +277,17 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 
   // ---------------- per-thread loader state (K-tile invariant) -----------------
   const int krow8 = tid >> 3;  // KC: row within a 32-row pass
-  // KC: quad within the 32-wide k row.  DMA: the lane's PHYSICAL quad is tid & 7 (LDS-DMA is lane-linear); it holds logical
-  // quad (tid & 7) ^ so_swz(row) - the same for every pass j, since so_swz only looks at row bits 1..4 and passes are 32+ rows apart
-  const int kq = DMA ? ((tid & 7) ^ so_swz(krow8)) : (tid & 7);
+  // KC: the lane's PHYSICAL quad is tid & 7 (LDS-DMA is lane-linear); it holds logical quad (tid & 7) ^ so_swz(row) - the same
+  // for every pass j, since so_swz only looks at row bits 1..4 and passes are 32+ rows apart
+  const int kq = (tid & 7) ^ so_swz(krow8);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // in an SGPR: LDS-DMA bases (M0) are wave-uniform
-  (void)wave_u;
   typedef __attribute__((address_space(3))) void* so_lds_ptr;
-  // one staged quad: into the register stage, or straight into LDS stage `fill_st` (rows 8 * wave .. + 7 of pass j)
-#define SO_EMIT_A(j, off)                                                                                                        \
-  do {                                                                                                                           \
-    if constexpr (DMA)                                                                                                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (so_lds_ptr)(As + fill_st * A_STAGE + (8 * wave_u + RPP * (j)) * 32), 16,     \
-                                               (int)(off), 0, 0, 0);                                                             \
-    else                                                                                                                         \
-      dst[j] = so_bload(rA, (off));                                                                                              \
-  } while (0)
-#define SO_EMIT_B(j, off)                                                                                                        \
-  do {                                                                                                                           \
-    if constexpr (DMA)                                                                                                           \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (so_lds_ptr)(Bs + fill_st * B_STAGE + (8 * wave_u + RPP * (j)) * 32), 16,     \
-                                               (int)(off), 0, 0, 0);                                                             \
-    else                                                                                                                         \
-      dst[j] = so_bload(rB, (off));                                                                                              \
-  } while (0)
+  // one staged quad of pass j -> LDS stage `fill_st`, KB number wave + NW * j of the tile (KC: rows 8 * that ..+7; MC: k-rows
+  // (256 / rows) * that ..)
+#define SO_EMIT_A(j, off) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (so_lds_ptr)(As + fill_st * A_STAGE + (wave_u + NW * (j)) * 256), 16, (int)(off), 0, 0, 0)
+#define SO_EMIT_B(j, off) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (so_lds_ptr)(Bs + fill_st * B_STAGE + (wave_u + NW * (j)) * 256), 16, (int)(off), 0, 0, 0)
   // A operand, KC: element offset of the row's origin pixel and its (h0, w0); invalid rows get h0 = -2^28
   int a_org[AJ], a_h0[AJ], a_w0[AJ];
   (void)a_org; (void)a_h0; (void)a_w0;
@@ -370,15 +325,10 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       }
     }
   }
-  const int a_mq = tid % AQPR, a_kr = tid / AQPR;  // MC mapping
-  const int b_mq = tid % BQPR, b_kr = tid / BQPR;
-  int a_st[4], b_st[4];  // MC: LDS offsets of the four transposed rows this thread writes
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ar = a_mq * 4 + i, br = b_mq * 4 + i;
-    a_st[i] = ar * 32 + ((((a_kr * AJ) >> 2) ^ so_swz(ar)) << 2) + ((a_kr * AJ) & 3);
-    b_st[i] = br * 32 + ((((b_kr * BJ) >> 2) ^ so_swz(br)) << 2) + ((b_kr * BJ) & 3);
-  }
+  // MC mapping: pass j of wave w is KB number w + NW * j = k-rows (w + NW * j) * (256 / rows) ..; within it lane l holds quad
+  // l % QPR of k-row l / QPR.  => the thread's k-row in pass j = a_kr + APASS * j
+  const int a_mq = lane % AQPR, a_kr = wave * (64 / AQPR) + lane / AQPR;
+  const int b_mq = lane % BQPR, b_kr = wave * (64 / BQPR) + lane / BQPR;
   // B operand, KC (weights / plain rows): element offset of each row, -1 if out of range
   int b_row[BJ];
   (void)b_row;
@@ -401,8 +351,6 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     w_s = tap - w_r * p.S;
   }
 
-  f32x4 ra[AJ], rb[BJ];
-
   const int nkt = (p.K + BK - 1) / BK;
   const int kt_begin = split * p.ktps;
   const int kt_end = (kt_begin + p.ktps > nkt) ? nkt : kt_begin + p.ktps;
@@ -413,30 +361,41 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // DGRAD with in-place weights (B_MC): (ko, ts, tr) of the thread's next k row
   int dg_ko = 0, dg_ts = 0, dg_tr = 0, dg_dko = 0, dg_dts = 0, dg_dtr = 0;
   (void)dg_ko; (void)dg_ts; (void)dg_tr; (void)dg_dko; (void)dg_dts; (void)dg_dtr;
+  // two strides: from pass j to pass j + 1 (BPASS k-rows) and from the last pass of a tile to the first of the next
+  int dg_pko = 0, dg_pts = 0, dg_ptr = 0, wg_pw = 0, wg_ph = 0, wg_pn = 0;
+  (void)dg_pko; (void)dg_pts; (void)dg_ptr; (void)wg_pw; (void)wg_ph; (void)wg_pn;
   if constexpr (MODE == MODE_DGRAD && B_MC) {
-    const int kk = kt_begin * BK + b_kr * BJ;
+    const int kk = kt_begin * BK + b_kr;
     const int tapi = kk / p.Ko;
     dg_ko = kk - tapi * p.Ko;
     dg_tr = tapi / p.TS;
     dg_ts = tapi - dg_tr * p.TS;
-    const int adv = BK - (BJ - 1);
+    const int adv = BK - (BJ - 1) * BPASS;
     const int q1 = adv / p.Ko;
     dg_dko = adv - q1 * p.Ko;
     dg_dtr = q1 / p.TS;
     dg_dts = q1 - dg_dtr * p.TS;
+    const int q2 = BPASS / p.Ko;
+    dg_pko = BPASS - q2 * p.Ko;
+    dg_ptr = q2 / p.TS;
+    dg_pts = q2 - dg_ptr * p.TS;
   }
   if constexpr (MODE == MODE_WGRAD) {
-    const int kk = kt_begin * BK + b_kr * BJ;
+    const int kk = kt_begin * BK + b_kr;
     const int hw = p.Ho * p.Wo;
     wg_n = kk / hw;
     const int rem = kk - wg_n * hw;
     wg_ho = rem / p.Wo;
     wg_wo = rem - wg_ho * p.Wo;
-    const int adv = BK - (BJ - 1);          // from the last quad of a tile to the first quad of the next
+    const int adv = BK - (BJ - 1) * BPASS;  // from the last pass of a tile to the first pass of the next
     const int q1 = adv / p.Wo;
     wg_dw = adv - q1 * p.Wo;
     wg_dn = q1 / p.Ho;
     wg_dh = q1 - wg_dn * p.Ho;
+    const int q2 = BPASS / p.Wo;
+    wg_pw = BPASS - q2 * p.Wo;
+    wg_pn = q2 / p.Ho;
+    wg_ph = q2 - wg_pn * p.Ho;
   }
 
   // Channel counts that are a multiple of BK (every layer but the image-facing ones) put a whole K tile inside ONE
@@ -470,8 +429,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 
   // Issue the (branch-free) global loads of K tile `kt` into ra/rb.  Tiles at or beyond kt_end read as zeros
   // without touching memory (every lane goes out of range), which lets the main loop run without tail branches.
-  auto load_a = [&](int kt, f32x4 (&dst)[AJ], int fill_st) {
-    (void)fill_st;
+  auto load_a = [&](int kt, int fill_st) {
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!A_MC) {
@@ -521,14 +479,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       const bool colok = col < p.M;
 #pragma unroll
       for (int j = 0; j < AJ; ++j) {
-        const int kk = k0 + a_kr * AJ + j;
+        const int kk = k0 + a_kr + APASS * j;
         const bool ok = colok & (kk < Klim);
         SO_EMIT_A(j, (((unsigned)(kk * p.lda + col) * 4u) | (ok ? 0u : SO_OOB)));
       }
     }
   };
-  auto load_b = [&](int kt, f32x4 (&dst)[BJ], int fill_st) {
-    (void)fill_st;
+  auto load_b = [&](int kt, int fill_st) {
     const int k0 = kt * BK;
     const int Klim = kt < kt_end ? p.K : 0;
     if constexpr (!B_MC) {
@@ -555,13 +512,13 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
       const int col = n0 + b_mq * 4;
 #pragma unroll
       for (int j = 0; j < BJ; ++j) {
-        const int kk = k0 + b_kr * BJ + j;
+        const int kk = k0 + b_kr + BPASS * j;
         if constexpr (MODE == MODE_DGRAD) {
           if (uni_k) {
             // Ko % 32 == 0: the whole K tile sits in one class tap (decoded once per tile by load_a, block-uniform);
             // only the output channel ko = first ko of the tile + this thread's k row differs between threads
             const int r = d_r0 + p.stride * u_cur_r, s = d_s0 + p.stride * u_cur_s;
-            const int ko = u_cur_c0 + b_kr * BJ + j;
+            const int ko = u_cur_c0 + b_kr + BPASS * j;
             const bool ok = (kk < Klim) & (col < p.N);
             SO_EMIT_B(j, (((unsigned)((ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
             continue;
@@ -570,22 +527,15 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int r = d_r0 + p.stride * dg_tr, s = d_s0 + p.stride * dg_ts;
           const bool ok = (kk < Klim) & (col < p.N);
           SO_EMIT_B(j, (((unsigned)((dg_ko * (p.R * p.S) + (r * p.S + s)) * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
-          if (j + 1 < BJ) {
-            dg_ko += 1;
-            const bool c1 = dg_ko == p.Ko;
-            dg_ko = c1 ? 0 : dg_ko;
-            dg_ts += c1 ? 1 : 0;
-            const bool c2 = dg_ts == p.TS;
-            dg_ts = c2 ? 0 : dg_ts;
-            dg_tr += c2 ? 1 : 0;
-          } else {
-            dg_ko += dg_dko;
+          {   // next pass (BPASS k-rows further) / first pass of the next tile
+            const int sko = j + 1 < BJ ? dg_pko : dg_dko, sts = j + 1 < BJ ? dg_pts : dg_dts, str_ = j + 1 < BJ ? dg_ptr : dg_dtr;
+            dg_ko += sko;
             const bool c1 = dg_ko >= p.Ko;
             dg_ko -= c1 ? p.Ko : 0;
-            dg_ts += dg_dts + (c1 ? 1 : 0);
+            dg_ts += sts + (c1 ? 1 : 0);
             const bool c2 = dg_ts >= p.TS;
             dg_ts -= c2 ? p.TS : 0;
-            dg_tr += dg_dtr + (c2 ? 1 : 0);
+            dg_tr += str_ + (c2 ? 1 : 0);
           }
         } else if constexpr (MODE == MODE_WGRAD) {
           // (wg_n, wg_ho, wg_wo) = output pixel of k row kk, carried from quad to quad and from tile to tile
@@ -593,49 +543,21 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
           const int wi = wg_wo * p.stride - p.pad + w_s;
           const bool ok = (kk < Klim) & w_colvalid & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
           SO_EMIT_B(j, (((unsigned)(((wg_n * p.H + hi) * p.W + wi) * p.ldb + w_c) * 4u) | (ok ? 0u : SO_OOB)));
-          if (j + 1 < BJ) {  // next k row = next output pixel
-            wg_wo += 1;
-            const bool cw = wg_wo == p.Wo;
-            wg_wo = cw ? 0 : wg_wo;
-            wg_ho += cw ? 1 : 0;
-            const bool ch = wg_ho == p.Ho;
-            wg_ho = ch ? 0 : wg_ho;
-            wg_n += ch ? 1 : 0;
-          } else {           // first k row of the next tile: 32 - (BJ - 1) pixels ahead
-            wg_wo += wg_dw;
+          {   // next pass (BPASS output pixels further) / first pass of the next tile
+            const int sw = j + 1 < BJ ? wg_pw : wg_dw, sh = j + 1 < BJ ? wg_ph : wg_dh, sn = j + 1 < BJ ? wg_pn : wg_dn;
+            wg_wo += sw;
             const bool cw = wg_wo >= p.Wo;
             wg_wo -= cw ? p.Wo : 0;
-            wg_ho += wg_dh + (cw ? 1 : 0);
+            wg_ho += sh + (cw ? 1 : 0);
             const bool ch = wg_ho >= p.Ho;
             wg_ho -= ch ? p.Ho : 0;
-            wg_n += wg_dn + (ch ? 1 : 0);
+            wg_n += sn + (ch ? 1 : 0);
           }
         } else {
           const bool ok = (kk < Klim) & (col < p.N);
           SO_EMIT_B(j, (((unsigned)(kk * p.ldb + col) * 4u) | (ok ? 0u : SO_OOB)));
         }
       }
-    }
-  };
-
-  auto store_a = [&](int st, const f32x4 (&src)[AJ]) {
-    float* as = As + st * A_STAGE;
-    if constexpr (!A_MC) {
-#pragma unroll
-      for (int j = 0; j < AJ; ++j)
-        *reinterpret_cast<f32x4*>(as + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
-    } else {
-      so_store_transposed<AJ>((unsigned)(uintptr_t)as, a_st, src);
-    }
-  };
-  auto store_b = [&](int st, const f32x4 (&src)[BJ]) {
-    float* bs = Bs + st * B_STAGE;
-    if constexpr (!B_MC) {
-#pragma unroll
-      for (int j = 0; j < BJ; ++j)
-        *reinterpret_cast<f32x4*>(bs + (krow8 + RPP * j) * LDK + kq * 4) = src[j];
-    } else {
-      so_store_transposed<BJ>((unsigned)(uintptr_t)bs, b_st, src);
     }
   };
 
@@ -670,14 +592,22 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * WTM + i * 32 + li;
-      const int off = (A_MC || DMA) ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
-      af[i] = *reinterpret_cast<const f32x4*>(as + off);
+      if constexpr (A_MC) {   // [32 k][BM rows]: four ds_read_b32 at k, k+1, k+2, k+3 of this lane half
+        const float* q = as + (kc * 8 + lh * 4) * BM + row;
+        af[i][0] = q[0]; af[i][1] = q[BM]; af[i][2] = q[2 * BM]; af[i][3] = q[3 * BM];
+      } else {
+        af[i] = *reinterpret_cast<const f32x4*>(as + row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)));
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * WTN + j * 32 + li;
-      const int off = (B_MC || DMA) ? row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)) : row * LDK + kc * 8 + lh * 4;
-      bf[j] = *reinterpret_cast<const f32x4*>(bs + off);
+      if constexpr (B_MC) {
+        const float* q = bs + (kc * 8 + lh * 4) * BN + row;
+        bf[j][0] = q[0]; bf[j][1] = q[BN]; bf[j][2] = q[2 * BN]; bf[j][3] = q[3 * BN];
+      } else {
+        bf[j] = *reinterpret_cast<const f32x4*>(bs + row * 32 + ((kc * 8) ^ (lh * 4) ^ (so_swz(row) << 2)));
+      }
     }
   };
   auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
@@ -702,7 +632,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #define SO_ABLATE 0
 #endif
   // SO_ABLATE (tools/ablate_igemm.sh, measurement builds only; results are WRONG for any non-zero value): drop one ingredient
-  // of the K loop to see what the loop is bound by - 1: MFMAs, 2: LDS stores, 4: global loads, 8: the barrier, 16: LDS reads.
+  // of the K loop to see what the loop is bound by - 1: MFMAs, 4: the LDS-DMA fills, 8: the barrier, 16: LDS reads.
 #if SO_ABLATE & 16
 #define SO_READ_FRAG(...)
 #else
@@ -714,121 +644,37 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #else
 #define SO_MMA(a, b) mma(a, b)
 #endif
-#if SO_ABLATE & 2
-#define SO_STORE_A(st, r) asm volatile("" :: "v"(r[0][0]), "v"(r[AJ - 1][3]))
-#define SO_STORE_B(st, r) asm volatile("" :: "v"(r[0][0]), "v"(r[BJ - 1][3]))
-#else
-#define SO_STORE_A(st, r) store_a(st, r)
-#define SO_STORE_B(st, r) store_b(st, r)
-#endif
 #if SO_ABLATE & 4
-#define SO_LOAD_A(kt, r)
-#define SO_LOAD_B(kt, r)
+#define SO_FILL(kt, st)
 #else
-#define SO_LOAD_A(kt, r) load_a(kt, r, 0)
-#define SO_LOAD_B(kt, r) load_b(kt, r, 0)
+#define SO_FILL(kt, st) do { load_a(kt, st); load_b(kt, st); } while (0)
 #endif
 #if SO_ABLATE & 8
 #define SO_SYNC()
 #else
-// (transposed staging writes are inline asm, invisible to the compiler's waitcnt insertion: drain them by hand)
-#define SO_SYNC() do { if constexpr (A_MC || B_MC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+#define SO_SYNC() __syncthreads()
 #endif
 
-  // Software pipeline, TWO register stages (round 5; tiles with one or two accumulators per wave).  While tile t is multiplied out of LDS[t & 1], tile t+1 goes from its
-  // register stage into LDS[(t+1) & 1] and the loads of tile t+3 are issued into the stage it has just vacated; tile t+2 is
-  // in flight in the other stage.  A global load therefore has TWO whole K tiles (32+ MFMAs per wave, >= 2000 cycles) to
-  // land before its ds_write needs it.  Round 1-4 ordering for the record: ONE stage, loads issued behind the third / fourth
-  // MFMA group of tile t and consumed behind the first / second group of tile t+1 - 8 MFMAs = 512 cycles of cover against an
-  // L2 latency of 500-900 cycles under load; the ISA showed `s_waitcnt vmcnt(3..0)` in front of every ds_write (and a
-  // vmcnt(0) on the loop's back edge in the weight-gradient kernels), and the ablation builds (profiles/r05_igemm_ablation.txt)
-  // put 10-25 % of the kernel time on exactly those waits.  The loop is unrolled by two so that both stages and both LDS
-  // buffers are addressed statically; the loaders still see the tiles in order (their incremental index state relies on it).
-  // The 128x128 / 4-wave tile (four accumulators per wave, 160+ VGPRs) has no room for a second stage: it keeps ONE stage
-  // with the same early issue point (behind the first / second MFMA group), i.e. one whole K tile of cover.
-  constexpr bool TWO_STAGE = !DMA && NW == 4 && TM * TN <= 2;   // (8-wave tiles: two blocks per CU need <= 128 VGPRs)
-  f32x4 ra1[TWO_STAGE ? AJ : 1], rb1[TWO_STAGE ? BJ : 1];
-  (void)ra1; (void)rb1;
-  if constexpr (DMA) {
-    load_a(kt_begin, ra, 0);    // (ra / rb are unused in this mode: the quads go straight into LDS stage 0)
-    load_b(kt_begin, rb, 0);
-  } else {
-    f32x4 ra0[AJ], rb0[BJ];
-    load_a(kt_begin, ra0, 0);
-    load_b(kt_begin, rb0, 0);
-    load_a(kt_begin + 1, ra, 0);
-    load_b(kt_begin + 1, rb, 0);
-    if constexpr (TWO_STAGE) {
-      load_a(kt_begin + 2, ra1, 0);
-      load_b(kt_begin + 2, rb1, 0);
-    }
-    store_a(0, ra0);
-    store_b(0, rb0);
-  }
+  // K loop.  Two LDS stages; the fill of tile t+1 is issued at the top of tile t into the stage all waves left at the barrier
+  // that ended tile t-1, and is drained by the vmcnt(0) hipcc puts in front of the barrier that ends tile t (an LDS-DMA is a
+  // pending LDS write on the VM counter): one whole tile - 16+ MFMAs per wave, times the blocks sharing the CU - to land.
+  // sched_barrier(0) around that barrier keeps the MFMAs (which touch no memory) from sinking below it; the loop is unrolled
+  // by two so that both stages are addressed statically, with no exit from the middle of the body (a second exit makes the
+  // accumulators live across a merge point and hipcc copies them).  The loaders see the tiles in order (their incremental
+  // index state relies on it).  History of this loop: rounds 1-4 staged through registers (loads consumed 512 cycles after
+  // issue; vmcnt(3..0) in front of every ds_write), round 5 first deepened that to two register stages, then removed the
+  // registers altogether (profiles/r05_igemm_ablation.txt, r05_*_ab.txt).
+  load_a(kt_begin, 0);
+  load_b(kt_begin, 0);
 #if SO_ABLATE & 16
   read_frag(0, 0, fa[0], fb[0]);
   read_frag(0, 1, fa[1], fb[1]);
 #endif
-  if constexpr (A_MC || B_MC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // one K tile: multiply LDS[CUR]; stage registers (sa, sb) -> LDS[CUR ^ 1]; refill them with tile `kt_load`.  Each burst of
-  // ds_write / buffer_load issues in the shadow of a 4-MFMA group; sched_barrier(0x6) pins memory ops and MFMAs in this
-  // order while the address arithmetic (VALU / SALU) floats.
-  // sched_barrier(0) in front of each staging burst: the register shuffles of the transposed stores (v_mov into adjacent
-  // pairs for ds_write_b64 / b128) are VALU and would otherwise float to the top of the tile - dragging the s_waitcnt vmcnt
-  // of the loads they read with them (seen in the ISA: vmcnt(1) before the first MFMA of every tile).
-#define SO_KTILE(CUR, sa, sb, kt_load)      \
-  do {                                      \
-    SO_READ_FRAG(CUR, 0, fa[0], fb[0]);     \
-    SO_READ_FRAG(CUR, 1, fa[1], fb[1]);     \
-    SO_SB();                                \
-    SO_MMA(fa[0], fb[0]);                   \
-    __builtin_amdgcn_sched_barrier(0);      \
-    SO_STORE_A((CUR) ^ 1, sa);              \
-    SO_LOAD_A(kt_load, sa);                 \
-    SO_READ_FRAG(CUR, 2, fa[0], fb[0]);     \
-    SO_SB();                                \
-    SO_MMA(fa[1], fb[1]);                   \
-    __builtin_amdgcn_sched_barrier(0);      \
-    SO_STORE_B((CUR) ^ 1, sb);              \
-    SO_LOAD_B(kt_load, sb);                 \
-    SO_READ_FRAG(CUR, 3, fa[1], fb[1]);     \
-    SO_SB();                                \
-    SO_MMA(fa[0], fb[0]);                   \
-    SO_SB();                                \
-    SO_MMA(fa[1], fb[1]);                   \
-    SO_SB();                                \
-    SO_SYNC();                              \
-  } while (0)
-  // the last tile of an odd trip count: nothing left to stage
-#define SO_KTILE_LAST(CUR)                  \
-  do {                                      \
-    SO_READ_FRAG(CUR, 0, fa[0], fb[0]);     \
-    SO_READ_FRAG(CUR, 1, fa[1], fb[1]);     \
-    SO_SB();                                \
-    SO_MMA(fa[0], fb[0]);                   \
-    SO_SB();                                \
-    SO_READ_FRAG(CUR, 2, fa[0], fb[0]);     \
-    SO_SB();                                \
-    SO_MMA(fa[1], fb[1]);                   \
-    SO_SB();                                \
-    SO_READ_FRAG(CUR, 3, fa[1], fb[1]);     \
-    SO_SB();                                \
-    SO_MMA(fa[0], fb[0]);                   \
-    SO_SB();                                \
-    SO_MMA(fa[1], fb[1]);                   \
-  } while (0)
-
-  // LDS-DMA form: the fill of tile t+1 is issued at the top of tile t into the stage all waves left at the barrier that ended
-  // tile t-1, and is drained by the vmcnt(0) hipcc puts in front of the barrier that ends tile t: one whole tile to land.
-  // sched_barrier(0) around that barrier keeps the MFMAs (which touch no memory) from sinking below it.
-#define SO_KTILE_DMA(CUR, kt_next)                                  \
+#define SO_KTILE(CUR, kt_next)                                      \
   do {                                                              \
-    if ((kt_next) < kt_end) {                                       \
-      SO_LOAD_A_DMA(kt_next, (CUR) ^ 1);                            \
-      SO_LOAD_B_DMA(kt_next, (CUR) ^ 1);                            \
-    }                                                               \
+    if ((kt_next) < kt_end) SO_FILL(kt_next, (CUR) ^ 1);            \
     __builtin_amdgcn_sched_barrier(0);                              \
     SO_READ_FRAG(CUR, 0, fa[0], fb[0]);                             \
     SO_READ_FRAG(CUR, 1, fa[1], fb[1]);                             \
@@ -848,39 +694,14 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
     SO_SYNC();                                                      \
     __builtin_amdgcn_sched_barrier(0);                              \
   } while (0)
-#if SO_ABLATE & 4
-#define SO_LOAD_A_DMA(kt, st)
-#define SO_LOAD_B_DMA(kt, st)
-#else
-#define SO_LOAD_A_DMA(kt, st) load_a(kt, ra, st)
-#define SO_LOAD_B_DMA(kt, st) load_b(kt, rb, st)
-#endif
 
-  if constexpr (DMA) {
+  {
     int kt = kt_begin;
     for (; kt + 1 < kt_end; kt += 2) {
-      SO_KTILE_DMA(0, kt + 1);
-      SO_KTILE_DMA(1, kt + 2);
+      SO_KTILE(0, kt + 1);
+      SO_KTILE(1, kt + 2);
     }
-    if (kt < kt_end) SO_KTILE_DMA(0, kt + 1);
-  } else if constexpr (TWO_STAGE) {
-    // (no break out of the middle of the body: a second exit makes the register stages live across a merge point and the
-    //  compiler rotates them with v_mov copies behind a vmcnt(0))
-    int kt = kt_begin;
-    for (; kt + 1 < kt_end; kt += 2) {
-      SO_KTILE(0, ra, rb, kt + 3);
-      SO_KTILE(1, ra1, rb1, kt + 4);
-    }
-    if (kt < kt_end) {
-      SO_KTILE_LAST(0);
-      __syncthreads();   // the epilogue reuses the LDS stages as its transposition patches
-    }
-  } else {
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      SO_KTILE(cur, ra, rb, kt + 2);
-      cur ^= 1;
-    }
+    if (kt < kt_end) SO_KTILE(0, kt + 1);
   }
 
   // ---------------- epilogue ----------------
@@ -1118,9 +939,8 @@ void so_prof_end(int slot, hipStream_t stream) {
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
 static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
   SoIgemm p = p_in;
-  constexpr bool DMA = !A_MC && !B_MC;
-  constexpr int A_STAGE = BM * ((A_MC || DMA) ? 32 : 36);
-  constexpr int B_STAGE = BN * ((B_MC || DMA) ? 32 : 36);
+  constexpr int A_STAGE = BM * 32;   // floats per LDS stage, either layout ([rows][32 k] or [32 k][rows])
+  constexpr int B_STAGE = BN * 32;
   constexpr size_t lds = (size_t)(2 * (A_STAGE + B_STAGE)) * sizeof(float);
   auto kern = so_igemm_kernel<MODE, A_MC, B_MC, BM, BN, NW>;
   static bool attr_set = false;

@@ -16,6 +16,26 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def fixture_cases_run_on_committed_plans(request):
+    """The cases compared with committed fixtures (three training steps of the small variants, the full-size steps and
+    generator pass) launch only layer shapes with a COMMITTED igemm plan (tools/gpu_make_plans.sh collects them from these
+    very tests): the kernel choice, hence the split-K order, hence every bit is the same on every box, which lets
+    tests/golden/full/routes.json pin their acceptance routes strictly (round 4: measured per process, route changes were
+    warnings)."""
+    import os
+
+    import shineon_virtual_tryon_amd as pkg
+
+    pinned = any(t in request.node.name for t in ("three_training_steps", "full_size_generator_pass", "two_full_iterations"))
+    L = pkg.lib()
+    before = L.so_igemm_plan_count()
+    yield
+    if pinned and not os.environ.get("SHINEON_PLANS_SAVE"):
+        assert L.so_igemm_plan_count() == before, (f"{L.so_igemm_plan_count() - before} layer shapes without a committed plan "
+                                                    "were measured: regenerate plans/gfx950.txt (tools/gpu_make_plans.sh)")
+
+
 def _ops():
     from shineon_virtual_tryon_amd import ops, ops_sams
 
