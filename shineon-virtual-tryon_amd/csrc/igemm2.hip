@@ -664,6 +664,41 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   // index state relies on it).  History of this loop: rounds 1-4 staged through registers (loads consumed 512 cycles after
   // issue; vmcnt(3..0) in front of every ds_write), round 5 first deepened that to two register stages, then removed the
   // registers altogether (profiles/r05_igemm_ablation.txt, r05_*_ab.txt).
+  const bool to_ws = p.splitk > 1;
+  // Wide path: each 32x32 accumulator tile is transposed through a wave-private LDS patch so that a lane owns
+  // four consecutive columns of one row and issues 16-byte stores (8 rows x 128 B per instruction) instead of
+  // sixteen 4-byte stores per tile.  Needs 16-byte aligned rows; otherwise the scalar path below is used.
+  const bool wide = (p.N & 3) == 0 &&
+                    (to_ws || ((p.ldc & 3) == 0 && (((uintptr_t)p.c) & 15) == 0 && (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
+                               (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0 &&
+                                           (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
+                               (!p.gate || (((uintptr_t)p.gate) & 15) == 0)));
+
+  // Weight gradients accumulate into the optimizer's gradient slab (res == c): the epilogue used to read the old values
+  // right before it stores - a dependent HBM / L2 latency per tile at the very end of a kernel whose K loop is short
+  // (K = the layer's pixel count).  With the staging registers gone there is room to fetch them up front.
+  constexpr bool PRE_RES = MODE == MODE_WGRAD && TM * TN <= 2;
+  f32x4 rres[PRE_RES ? TM : 1][PRE_RES ? TN : 1][4];
+  (void)rres;
+  bool pre_res = false;
+  if constexpr (PRE_RES) {
+    pre_res = wide && !to_ws && p.res != nullptr && (long long)p.M * p.ldres < (1ll << 29);
+    if (pre_res) {
+      const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (int)0x7FFFFFFF, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = m0 + wm * WTM + i * 32 + (lane >> 3) + 8 * q;
+            const int n = n0 + wn * WTN + j * 32 + (lane & 7) * 4;
+            const bool ok = (m < p.M) & (n < p.N);
+            rres[i][j][q] = so_bload(rR, (((unsigned)(m * p.ldres + n) * 4u) | (ok ? 0u : SO_OOB)));
+          }
+    }
+  }
+
   load_a(kt_begin, 0);
   load_b(kt_begin, 0);
 #if SO_ABLATE & 16
@@ -709,15 +744,6 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[0][r];
   }
-  const bool to_ws = p.splitk > 1;
-  // Wide path: each 32x32 accumulator tile is transposed through a wave-private LDS patch so that a lane owns
-  // four consecutive columns of one row and issues 16-byte stores (8 rows x 128 B per instruction) instead of
-  // sixteen 4-byte stores per tile.  Needs 16-byte aligned rows; otherwise the scalar path below is used.
-  const bool wide = (p.N & 3) == 0 &&
-                    (to_ws || ((p.ldc & 3) == 0 && (((uintptr_t)p.c) & 15) == 0 && (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
-                               (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0 &&
-                                           (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
-                               (!p.gate || (((uintptr_t)p.gate) & 15) == 0)));
   if (wide) {
     float* stg = smem + wave * (32 * LDK);
 #pragma unroll
@@ -746,7 +772,9 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
                   for (int k = 0; k < 4; ++k) if (n + k < p.nbias) v[k] += p.bias[n + k];
                 }
                 if (p.res) {
-                  const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + roff + n);
+                  f32x4 rv;
+                  if (PRE_RES && pre_res) rv = rres[PRE_RES ? i : 0][PRE_RES ? j : 0][q];
+                  else rv = *reinterpret_cast<const f32x4*>(p.res + roff + n);
                   v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
                 }
                 if (p.act != SO_ACT_NONE) {
