@@ -15,18 +15,15 @@
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  K may be permuted freely as long as A and B agree,
 //     so a lane-half reads FOUR consecutive k with one ds_read_b128 and feeds four MFMAs
 //     (k = kbase + 4*(lane>>5) + t for MFMA t).
-//   * LDS tiles are always [rows][32 k], row pitch 36 floats -> conflict-free ds_read_b128 for both operands.
-//     Two ways of getting there from HBM:
-//       KC ("k-contiguous" memory)  : the 16-byte quad a lane loads is a run of k -> stored as is
-//       MC ("mn-contiguous" memory) : the quad is a run of rows at one k; a lane loads the quads of 1/2/4
-//                                     consecutive k and writes them transposed (4 x ds_write_b32/b64/b128)
+//   * LDS stages are filled by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write (round 5).  The LDS
+//     image of a tile is the order in which the lanes fetch it:
+//       KC ("k-contiguous" memory)  : tile [rows][32 k], rows unpadded, k quads XOR-swizzled on the source side;
+//                                     fragments = ds_read_b128
+//       MC ("mn-contiguous" memory) : tile [32 k][rows] as it lies in memory, NOT transposed; fragments = 4 x ds_read_b32
 //     FPROP = KC x KC, DGRAD = KC x KC on transposed weights (or KC x MC in place), WGRAD = MC x MC.
 //   * BRANCH-FREE staging: operands are read through buffer descriptors; a lane that must see a zero (conv
-//     padding, ragged tile edge, K tail) issues the same buffer_load with an out-of-range offset and the
-//     hardware returns 0.  The K-tile body is one straight-line block, so the scheduler can slot the address
-//     arithmetic, the ds_writes and the next loads into the 64-cycle shadows of the fp32 MFMAs.
-//   * software pipeline, prefetch distance 2: while tile t is multiplied, tile t+1 is written to the other LDS
-//     buffer (its loads were issued during tile t-1) and the loads of tile t+2 are issued; one barrier per tile.
+//     padding, ragged tile edge, K tail) issues the same fill with an out-of-range offset and the hardware writes 0.
+//   * two LDS stages: the fill of tile t+1 is issued at the top of tile t and drained by the barrier that ends tile t.
 //   * index decode (k -> tap/channel, pixel -> n/h/w) uses a reciprocal-multiply division (operands < 2^24).
 //   * 256 threads = 4 waves (2x2); block tiles 64x64, 128x64, 64x128, 128x128; BK = 32.
 //   * deterministic split-K (slabs in a workspace + reduce kernel carrying the fused epilogue).
