@@ -115,6 +115,12 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
 /* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
+/* csrc/pgemm.hip: the Winograd-domain batched products (C[b] = A[b] B[b]^T, K % 64 == 0, >= 16 matrices, >= 768 output tiles) run
+ * on a PERSISTENT kernel that keeps its LDS-DMA pipeline running across output tiles; 1 = handled, 0 = not applicable (callers
+ * fall back to so_gemm_batched).  so_pgemm_enable(0) switches it off (A/B measurements). */
+int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, const float* B, int ldb, long long sb, float* C, int ldc,
+                long long sc, int batch, void* stream);
+void so_pgemm_enable(int on);
 /* 1 (default): the fused kernel's two LDS stages are filled by LDS-DMA (buffer_load ... lds); 0: through registers + ds_write */
 void so_wino_fused_dma(int on);
 

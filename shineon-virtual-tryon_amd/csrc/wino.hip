@@ -24,6 +24,8 @@
 #include "../../include/shineon_hip.h"
 #include "thin.h"   // so_prof_begin / so_prof_end (live HIP-event timing shared with the implicit-GEMM engine)
 
+extern "C" int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, const float* B, int ldb, long long sb, float* C,
+                           int ldc, long long sc, int batch, void* stream);   // csrc/pgemm.hip: 1 = done, 0 = not applicable
 extern "C" int so_gemm_batched(int transa, int transb, int M, int N, int K, const float* A, int lda, long long sa,
                                const float* B, int ldb, long long sb, float* C, int ldc, long long sc, int batch,
                                const float* alpha, const float* bias, const float* res, int ldres, long long sres, int act,
@@ -868,6 +870,9 @@ int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, 
   hipLaunchKernelGGL(wino_input_k, dim3(grid_for(T * (C >> 2))), dim3(256), 0, st, x, ldx, V, Nb, H, W, C, th, tw);
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
+  err = so_pgemm_nt((int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 16, stream);   // persistent short-K form
+  if (err == 1) err = 0;
+  else if (err == 0)
   err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 16, nullptr, nullptr, nullptr,
                         0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
   if (err) return err;
@@ -906,6 +911,9 @@ int so_wino4_conv3x3(const float* x, int ldx, const float* U, const float* bias,
   hipLaunchKernelGGL(wino4_input_k, dim3(grid_for(T * (C >> 2))), dim3(256), 0, st, x, ldx, V, Nb, H, W, C, th, tw);
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
+  err = so_pgemm_nt((int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 36, stream);   // persistent short-K form
+  if (err == 1) err = 0;
+  else if (err == 0)
   err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 36, nullptr, nullptr, nullptr,
                         0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
   if (err) return err;

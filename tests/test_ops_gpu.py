@@ -451,6 +451,38 @@ def test_adam_matches_torch(ops, cuda):
     assert_close(p, p_ref.detach(), atol=1e-6, what="adam")
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(1536, 256, 256, 36), (384, 512, 512, 36), (3072, 128, 512, 16), (1000, 132, 128, 16),
+                                         (770, 128, 192, 36), (96 * 12, 256, 1024, 16)])
+def test_persistent_winograd_gemm_is_bit_identical_to_the_engine(cuda, M, N, K, batch):
+    """csrc/pgemm.hip (persistent workgroups, LDS-DMA pipeline kept running across output tiles) against the general engine's
+    batched NT GEMM on Winograd-domain shapes, ragged M / N included: same tile, same k order, same MFMA sequence ->
+    torch.equal.  Run twice into a dirtied output (every element must be rewritten)."""
+    from shineon_virtual_tryon_amd import lib
+
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(batch, M, K, generator=g).to(cuda)
+    B = torch.randn(batch, N, K, generator=g).to(cuda)
+    ws = torch.empty(64 << 20, device=cuda)
+    ref = torch.empty(batch, M, N, device=cuda)
+    L.so_igemm_force(64, 64, 1)
+    try:
+        assert L.so_gemm_batched(0, 1, M, N, K, A.data_ptr(), K, M * K, B.data_ptr(), K, N * K, ref.data_ptr(), N, M * N, batch, None, None,
+                                 None, 0, 0, 0, 0.0, ws.data_ptr(), ws.numel() * 4, st) == 0
+    finally:
+        L.so_igemm_force(0, 0, 0)
+    for rep in range(2):
+        out = torch.full((batch, M, N), float("nan"), device=cuda)
+        rc = L.so_pgemm_nt(M, N, K, A.data_ptr(), K, M * K, B.data_ptr(), K, N * K, out.data_ptr(), N, M * N, batch, st)
+        assert rc == 1, rc
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+    # and against fp64 on a slice
+    want = A[3].double().cpu() @ B[3].double().cpu().T
+    assert (ref[3].double().cpu() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
 @pytest.mark.parametrize("n,h,w,c,ko,act,gated", [
     (2, 16, 12, 64, 32, 1, False),     # ReLU epilogue (VGG forward)
