@@ -244,6 +244,8 @@ int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long r
                    float scale, float* out, int accumulate, float* ws, void* stream);
 int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
                    float* da, int ldda, long long rows, int C, int accumulate, int relu_gate, void* stream);
+/* out[0] = ((a[0] + b[0]) + c[0]) + d[0] (c, d may be NULL): the sum of the loss terms (unet_mask_model.py:190) */
+int so_scalar_sum(const float* a, const float* b, const float* c, const float* d, float* out, void* stream);
 
 /* tanh / sigmoid / mask blend of UnetMaskModel.forward (unet_mask_model.py:84-86,126-129), one frame:
  * o: [pix][>=4] network output; cloth: [pix][>=3]; outputs rendered [pix][3], mask [pix][1],

@@ -996,6 +996,20 @@ int so_l1_loss_fwd(const float* a, int lda, const float* b, int ldb, long long r
   return SO_LAUNCH_CHECK();
 }
 
+// out[0] = ((a + b) + c) + d, left to right like the chain of scalar additions it replaces (c, d may be null)
+__global__ void scalar_sum_k(const float* a, const float* b, const float* c, const float* d, float* out) {
+  float s = a[0] + b[0];
+  if (c) s += c[0];
+  if (d) s += d[0];
+  out[0] = s;
+}
+
+int so_scalar_sum(const float* a, const float* b, const float* c, const float* d, float* out, void* stream) {
+  if (!a || !b || !out) return SO_ERR_SHAPE;
+  hipLaunchKernelGGL(scalar_sum_k, dim3(1), dim3(1), 0, (hipStream_t)stream, a, b, c, d, out);
+  return SO_LAUNCH_CHECK();
+}
+
 int so_l1_loss_bwd(const float* a, int lda, const float* b, int ldb, const float* gout, float scale,
                    float* da, int ldda, long long rows, int C, int accumulate, int relu_gate, void* stream) {
   if (rows * C <= 0) return 0;

@@ -536,14 +536,20 @@ class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
         L = lib()
-        xs = [to_rows(x) for x in xs]
         n, _, h, w = xs[0].shape
         cs = [x.shape[1] for x in xs]
         ct = sum(cs)
         out = nhwc_empty(n, h, w, ct, xs[0].device)
         off = 0
         for x, c in zip(xs, cs):
-            check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * off, ct, c, n * h * w, 0, _stream()), "copy2d")
+            _require_cuda(x)
+            if x.dtype != torch.float32:
+                raise TypeError("fp32 only")
+            if _is_rows(x):
+                check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * off, ct, c, n * h * w, 0, _stream()), "copy2d")
+            else:   # planar (batch tensors): transposed straight into its channel range, no private NHWC copy first
+                src = x if x.is_contiguous() else x.contiguous()
+                check(L.so_nchw_to_nhwc(src.data_ptr(), out.data_ptr() + 4 * off, ct, n, c, c, h * w, _stream()), "nchw_to_nhwc")
             off += c
         ctx.cs = cs
         return out
@@ -1248,6 +1254,45 @@ def l1_loss(a, b, weight=1.0):
     return _L1LossFn.apply(a, b, float(weight))
 
 
+class _ScalarSumFn(torch.autograd.Function):
+    """((a + b) + c) + d of 0-dim loss terms in one launch - the same left-to-right additions as `a + b + c + d`, each of
+    which is a kernel of its own inside the captured step; every term's gradient is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+        p = [t.data_ptr() for t in terms] + [None] * (4 - len(terms))
+        check(lib().so_scalar_sum(p[0], p[1], p[2], p[3], out.data_ptr(), _stream()), "scalar_sum")
+        ctx.n = len(terms)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (gout,) * ctx.n
+
+
+_ZERO = {}
+
+
+def zero_scalar(device):
+    """A constant 0-dim zero (the n_frames_total = 1 placeholders of the *_prev terms and of the flow-mask penalty)."""
+    key = (device.type, device.index)
+    z = _ZERO.get(key)
+    if z is None:
+        z = _ZERO[key] = torch.zeros((), dtype=torch.float32, device=device)
+    return z
+
+
+def scalar_sum(*terms):
+    """Sum of 2..4 scalar loss terms, added left to right (bit-identical to chained `+`)."""
+    if not (2 <= len(terms) <= 4) or not all(t.is_cuda and t.dim() == 0 and t.dtype == torch.float32 for t in terms):
+        out = terms[0]
+        for t in terms[1:]:
+            out = out + t
+        return out
+    return _ScalarSumFn.apply(*terms)
+
+
 class _TryonComposeFn(torch.autograd.Function):
     """tanh / sigmoid / blend of UnetMaskModel.forward for one frame (unet_mask_model.py:84-86,126-129)."""
 
@@ -1658,26 +1703,28 @@ def vgg_target_features(y, cfg, params):
     for item in cfg:
         n2, ci, hh, ww = cur.shape
         if item[0] == "M":
-            out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
-            check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
+            out_pool = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
+            check(L.so_maxpool2_fwd(cur.data_ptr(), ci, out_pool.data_ptr(), ci, n2, hh, ww, ci, _stream()), "maxpool2_fwd")
         else:
             weight, bias = params[pi], params[pi + 1]
             pi += 2
             co = weight.shape[0]
             wk = _ohwi(weight, cpad=ci)
-            out = nhwc_empty(n2, hh, ww, co, dev)
+            o_ = nhwc_empty(n2, hh, ww, co, dev)
             mode = _wino_mode(ci, co, n2, hh, ww)
             if mode != "direct":
                 wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, (weakref.ref(weight), weight._version), False, mode == "fused",
                                                                f44=mode == "nonfused4"),
-                             bias, None, out.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, dev, fused=mode == "fused",
+                             bias, None, o_.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, dev, fused=mode == "fused",
                              f44=mode == "nonfused4")
             else:
-                check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), out.data_ptr(), co, n2, hh, ww, ci, co,
+                check(L.so_conv2d_fprop(cur.data_ptr(), ci, wk.data_ptr(), bias.data_ptr(), o_.data_ptr(), co, n2, hh, ww, ci, co,
                                         3, 3, 1, 1, ACT_RELU, 0.0, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_fprop")
             if item[1] is not None:
-                feats.append(out)
-        cur = out
+                feats.append(o_)
+            cur = o_
+            continue
+        cur = out_pool
     return feats
 
 

@@ -139,7 +139,7 @@ class UnetMaskModel(BaseModel):
             if n > 1:
                 prev = fn(-2)
                 return 0.5 * (curr + prev), curr, prev
-            return curr, curr, torch.zeros_like(curr)
+            return curr, curr, (ops.zero_scalar(curr.device) if curr.is_cuda else torch.zeros_like(curr))
 
         loss_image_l1, l1_curr, l1_prev = both(lambda i: ops.l1_loss(pt[i], im[i]))
         # a pipeline may have computed the target's VGG features ahead of the step (single-frame case only)
@@ -148,10 +148,12 @@ class UnetMaskModel(BaseModel):
         loss_tryon_mask_l1, m_curr, m_prev = both(lambda i: ops.l1_loss(tm[i], cm[i]))
         if fm is not None:
             loss_flow_mask_l1 = ops.tensor_sum(fm[-1]) * hp.pen_flow_mask
+        elif m_curr.is_cuda:
+            loss_flow_mask_l1 = ops.zero_scalar(m_curr.device)   # zeros_like(...) * pen_flow_mask (unet_mask_model.py:186-188)
         else:
             loss_flow_mask_l1 = torch.zeros_like(m_curr) * hp.pen_flow_mask
 
-        loss = loss_image_l1 + loss_image_vgg + loss_tryon_mask_l1 + loss_flow_mask_l1
+        loss = ops.scalar_sum(loss_image_l1, loss_image_vgg, loss_tryon_mask_l1, loss_flow_mask_l1)
 
         if not val and self.global_step % hp.display_count == 0:
             self.visualize(batch)

@@ -424,6 +424,27 @@ def test_l1_loss(ops, cuda):
     assert ops.l1_loss(a.to(cuda), a.to(cuda)).item() == 0.0
 
 
+def test_scalar_sum_adds_left_to_right(ops, cuda):
+    t = [torch.tensor(v, dtype=torch.float32, device=cuda, requires_grad=True) for v in (1e8, 1.0, -1e8, 3.0)]
+    for k in (2, 3, 4):
+        got = ops.scalar_sum(*t[:k])
+        want = t[0].detach() + t[1].detach()
+        for x in t[2:k]:
+            want = want + x.detach()
+        assert torch.equal(got.detach(), want), (k, got.item(), want.item())
+    g = torch.autograd.grad(ops.scalar_sum(*t) * 2.0, t)
+    assert all(float(x) == 2.0 for x in g)
+
+
+def test_cat_channels_takes_planar_sources_straight_into_the_slab(ops, cuda):
+    """get_and_cat_inputs on batch tensors: NCHW sources are transposed directly into their channel range."""
+    a, b, c = rnd(2, 22, 32, 24, seed=63).to(cuda), rnd(2, 3, 32, 24, seed=64).to(cuda), rnd(2, 1, 32, 24, seed=65).to(cuda)
+    rows = ops.activation(b, None)   # an NHWC-pitch tensor among planar ones
+    out = ops.cat_channels([a, rows, c])
+    assert torch.equal(out, torch.cat([a, b, c], 1))
+    assert out.permute(0, 2, 3, 1).is_contiguous()
+
+
 def test_tryon_compose_and_blend(ops, cuda):
     o, cloth = rnd(2, 4, 16, 12, seed=45), rnd(2, 3, 16, 12, seed=46)
 

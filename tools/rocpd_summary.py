@@ -105,6 +105,27 @@ def exclusive(db, prefix, lo=0.4, hi=0.8):
     print(f"exclusive attribution over {len(rows)} kernels, span {span / 1e6:.3f} ms -> {prefix}_exclusive.csv")
 
 
+def sequence(db, prefix, n_last):
+    """The last `n_last` dispatches in start order -> <prefix>_sequence.csv (one steady-state step when n_last = launches per
+    step): start offset, duration, queue / stream when the schema has them, grid size, kernel name."""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(rocpd_kernel_dispatch)")]
+    extra = [c for c in ("queue_id", "stream_id", "grid_size_x", "workgroup_size_x") if c in cols]
+    sel = "".join(f", d.{c}" for c in extra)
+    rows = con.execute(f"""select d.start, d.end, s.kernel_name{sel} from rocpd_kernel_dispatch d
+                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
+    rows = rows[-n_last:]
+    t0 = rows[0][0]
+    with open(prefix + "_sequence.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["start_us", "dur_us"] + extra + ["name"])
+        for r in rows:
+            w.writerow([round((r[0] - t0) / 1e3, 2), round((r[1] - r[0]) / 1e3, 2)] + list(r[3:]) + [r[2]])
+    print(f"{len(rows)} dispatches -> {prefix}_sequence.csv")
+
+
+if __name__ == "__main__" and len(sys.argv) > 4 and sys.argv[3] == "seq":
+    sequence(sys.argv[1], sys.argv[2], int(sys.argv[4]))
 if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "gaps":
     gaps(sys.argv[1])
     exclusive(sys.argv[1], sys.argv[2])
