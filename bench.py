@@ -43,7 +43,8 @@ NKEYS = 40
 KEY_NAMES = [f"{m}_{t}" for m in ("fprop", "dgrad", "wgrad", "gemm", "winograd_gemm")
              for t in ("64x64", "128x64", "64x128", "128x128", "128x128w8", "64x128w8", "thin4", "-")]
 KEY_NAMES[7] = "winograd_fused"   # csrc/wino.hip: FLOPs recorded = algorithmic (direct-convolution) FLOPs; executed = / 2.25
-WINOGRAD_KEY, WINOGRAD_FACTOR = 7, 2.25
+KEY_NAMES[39] = "winograd_pgemm"  # csrc/pgemm.hip: the Winograd-domain (F(4x4)) products that run in the persistent NT GEMM
+WINOGRAD_KEY, WINOGRAD_FACTOR, PGEMM_KEY = 7, 2.25, 39
 # algorithmic GFLOP per frame: GMM fwd+bwd 28.0; try-on step = U-Net 50.3 + VGG19 (2 fwd + 1 dgrad) 106.5
 GF_PER_FRAME = {"c1": 16.8, "c2": 28.0, "c3": 156.8, "c4": 184.8, "c5": None, "sams": 3131.4}  # None: the MFMA launches' own 2MNK sum
 # sams: 62 627 GF per bs = 4 x 5-frame step = the sum of 2MNK over every MFMA launch of the step as DIRECT convolutions
@@ -124,6 +125,33 @@ def sams_cpu_baseline(batch_size):
                       f"PyTorch CPU fp32: median {dt:.1f} s/step (min {times[0]:.1f}, max {times[2]:.1f})"}
 
 
+def ramp_clocks(step, seconds):
+    """Untimed: the step itself, repeated for about `seconds` of wall time before the warm-up steps.  The timed window of the
+    short configurations is 0.02 s (c1) to 0.13 s (c4); started right after the capture / CPU-side set-up it sometimes began on
+    the clock ramp out of idle (profiles/README.md: c1 1653 instead of 3930 frames/s, c3 615 instead of 800, same build).  The
+    sustained runs under profiles/ (>= 2 s) never showed it.  With several ranks the steps contain collectives, so every rank
+    runs the SAME number of steps: two are timed, the slowest rank's time fixes the count.  Returns the steps run."""
+    if seconds <= 0:
+        return 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    step()
+    torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t0) / 2
+    if so_trainer._collective():
+        t = torch.tensor([per_step], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_step = float(t.item())
+    n = max(0, min(20000, int(seconds / max(per_step, 1e-5)) - 2))
+    for i in range(n):
+        step()
+        if i % 4 == 3:
+            torch.cuda.synchronize()   # the host must not queue seconds of work ahead of the device
+    torch.cuda.synchronize()
+    return n + 2
+
+
 def dominant_roofline(ms, fl, by, cnt, traffic, traffic_source, timing):
     """The `roofline` entries of the kernel with the largest summed time.  `achieved` / `frac` are what the matrix pipe
     EXECUTES (<= 1 by construction - asserted); the direct-convolution (algorithmic) figure, which a Winograd kernel exceeds
@@ -137,7 +165,9 @@ def dominant_roofline(ms, fl, by, cnt, traffic, traffic_source, timing):
     alg_bytes = by[dom] / cnt[dom] if cnt[dom] and by[dom] > 0 else None
     return dom, {
         "bound": "mfma",
-        "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
+        "kernel": ("wino_fused_k (Winograd F(2x2,3x3), csrc/wino.hip)" if dom == WINOGRAD_KEY else
+                   "pgemm_nt_k (persistent NT GEMM of the Winograd F(4x4,3x3)-domain products, csrc/pgemm.hip)" if dom == PGEMM_KEY else
+                   f"so_igemm_kernel<{KEY_NAMES[dom]}>"),
         "achieved": executed, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": frac,
         "achieved_note": ("EXECUTED MFMA FLOPs / kernel time" + (": the Winograd F(2x2,3x3) kernel executes 1/2.25 of the "
                           "direct-convolution multiplications; algorithmic_* is the direct-convolution figure (2 x pixels x Ko x 9C, "
@@ -368,6 +398,7 @@ def run_c1(args, trainer, L):
                 dist.barrier()
             torch.cuda.synchronize()
 
+        log(f"clock ramp: {ramp_clocks(step, args.ramp_seconds)} untimed steps in {args.ramp_seconds:.1f} s")
         for _ in range(args.warmup):
             step()
         fence()
@@ -405,6 +436,7 @@ def run_c1(args, trainer, L):
         "warmup": args.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp32", "data": "synthetic",
         "config": {"workload": WORKLOADS["c1"], "config": "c1", "launch": "eager" if graph is None else "one hipGraph (forward)",
+                   "untimed_clock_ramp_s": args.ramp_seconds,
                    "batch_per_gpu": args.batch, "global_batch": world * args.batch, "frames_per_sample": 1, "parallelism": f"dp{world}",
                    "step_api": "shineon_virtual_tryon_amd.unet_mask_model.UnetMaskModel.forward"},
         "roofline": {**roof,
@@ -642,6 +674,8 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="c4: two sequential graphs (warp, then try-on) instead of "
                     "the two-stream schedule that overlaps the warp backward pass with the try-on stage")
     ap.add_argument("--no-hbm-table", action="store_true")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed: run the step for this long before the warm-up "
+                    "steps so that the timed window starts at sustained clocks (0 = off)")
     ap.add_argument("--vgg-split-bf16", action="store_true", help="NON-HEADLINE experiment: the frozen VGG19 chain of the "
                     "perceptual loss on the bf16 matrix cores (fp32 = hi + mid bf16 planes, 3 MFMAs per product, fp32 "
                     "accumulate; csrc/sb16.hip); everything else stays exact fp32.  Reported with its own dtype string.")
@@ -739,7 +773,9 @@ def main():
             f"gradient slabs " + ", ".join(f"{o.flat_grads.numel() * 4 / 1e6:.1f} MB" for o in
                                            ([engine.optw, engine.optu] if cfg == "c4" else [opt])) + f": {how}")
 
-    log(f"rank {rank}/{world}: models built, warm-up {args.warmup} steps")
+    n_ramp = ramp_clocks(step, args.ramp_seconds)
+    flush()
+    log(f"rank {rank}/{world}: models built, clock ramp {n_ramp} untimed steps in {args.ramp_seconds:.1f} s, warm-up {args.warmup} steps")
     for i in range(args.warmup):
         t_w = time.perf_counter()
         step()
@@ -864,6 +900,7 @@ def main():
                        # True: the warp model's BatchNorm running statistics are broadcast in synchronize(), not per step
                        # (DDP broadcasts per forward; rounds 1-3 timed that broadcast inside the c4 step)
                        "lazy_buffers": getattr(engine, "lazy_buffers", None) if cfg == "c4" else None,
+                       "untimed_clock_ramp_s": args.ramp_seconds,
                        "pipeline_gain_ms": getattr(engine, "pipeline_gain_ms", None) if cfg == "c4" else None,
                        "exchange_probe_ms": getattr(engine, "exchange_ms", None) if cfg == "c4" else None},
             "roofline": {

@@ -208,7 +208,7 @@ int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, cons
     attr_set = true;
   }
   const unsigned grid = 768;   // 256 CUs x 3 resident workgroups (50 KB LDS each), a multiple of 8
-  const int slot = so_prof_begin(4 * 8 + 0, 2.0 * M * N * (double)K * batch, M, N, K, (hipStream_t)stream);
+  const int slot = so_prof_begin(4 * 8 + 7 /* bench.py KEY_NAMES[39] = winograd_pgemm */, 2.0 * M * N * (double)K * batch, M, N, K, (hipStream_t)stream);
   so_prof_bytes(slot, 4.0 * batch * ((double)M * K + (double)K * N + (double)M * N));
   hipLaunchKernelGGL(pgemm_nt_k, dim3(grid), dim3(256), PG_LDS, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);

@@ -22,6 +22,8 @@ MODES = {0: "fprop", 1: "dgrad", 2: "wgrad", 3: "gemm"}
 def key_of(sym):
     if "wino_fused_k" in sym:
         return "winograd_fused"
+    if "pgemm_nt_k" in sym:
+        return "winograd_pgemm"
     m = re.match(r"_Z15so_igemm_kernelILi(\d)ELb[01]ELb[01]ELi(\d+)ELi(\d+)ELi(\d)EE", sym)
     if not m:
         return None

@@ -11,12 +11,18 @@ cd $R
 for CFG in c4 c1 c2 c3 c5 sams; do
   SO_PROF_DUMP=$OUT/${TAG}_${CFG}_igemm_launches.csv python3 bench.py --config $CFG > $OUT/${TAG}_bench_${CFG}.json 2> $OUT/${TAG}_bench_${CFG}.log
 done
+# 1b. sustained runs: >= 2 s of timed steps per configuration (the default 20-step window is 0.13 s on c4)
+for CS in "c4 400" "c1 2500" "c2 1200" "c3 500" "c5 200" "sams 5"; do
+  set -- $CS
+  python3 bench.py --config $1 --steps $2 --no-cpu-baseline --no-hbm-table 2> /dev/null | grep '^{' > $OUT/${TAG}_sustained_$1.json
+done
 # 2. kernel trace of the headline command
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
 timeout -k 5 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_c4 gaps > $OUT/${TAG}_kernel_trace_summary.txt 2>&1
+python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_c4 seq 1100 >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
 # 3. PMC passes (own runs, kernel-trace only): HBM read, HBM write per configuration; MFMA / SQ activity for the headline.
 #    Eager launches (--no-graph).  SAMS: the whole step and a bs = 1 slice both die under the counters (rounds 2 and 3), so its
 #    dominant kernel - the fused Winograd kernel on its most frequent layer, 128 -> 256 channels at 256x192, bs = 4 - is
@@ -31,13 +37,13 @@ done
 # unfiltered passes of rounds 2 and 3 killed the process; if this one survives, traffic.json [sams] comes from the step itself
 for PASS in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_pmc
-  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "wino_fused_k" -d /tmp/prof_pmc -o r -- python3 $R/bench.py --config sams --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-table > $OUT/${TAG}_pmc_sams_step_$PASS.log 2>&1
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "wino_fused_k" -d /tmp/prof_pmc -o r -- python3 $R/bench.py --config sams --batch 4 --steps 1 --warmup 1 --ramp-seconds 0 --no-cpu-baseline --no-hbm-table > $OUT/${TAG}_pmc_sams_step_$PASS.log 2>&1
   echo "sams step pmc $PASS rc=$?" >> $OUT/${TAG}_kernel_trace_summary.txt
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
   [ -n "$DB" ] && python3 $R/tools/rocpd_summary.py $DB $OUT/${TAG}_sams_step_$PASS >> $OUT/${TAG}_kernel_trace_summary.txt 2>&1
 done
 for CFG in c4 c2 c3; do
-  EXTRA="--steps 3 --warmup 1 --no-graph"
+  EXTRA="--steps 3 --warmup 1 --no-graph --ramp-seconds 0"
   PASSES=("FETCH_SIZE" "WRITE_SIZE")
   [ $CFG = c4 ] && PASSES+=("SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE")
   for PASS in "${PASSES[@]}"; do
@@ -55,4 +61,5 @@ for CFG in c4 c3 sams; do
   grep "exposed\|timed\|backend" $OUT/${TAG}_single_rank_rccl_${CFG}.log
 done
 for CFG in c4 c1 c2 c3 c5 sams; do tail -1 $OUT/${TAG}_bench_${CFG}.json | cut -c1-300; done
+for CFG in c4 c1 c2 c3 c5 sams; do echo "sustained $CFG: $(cut -c1-200 $OUT/${TAG}_sustained_${CFG}.json)"; done
 cat $OUT/${TAG}_kernel_trace_summary.txt
