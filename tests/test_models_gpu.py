@@ -38,7 +38,9 @@ def test_warp_model_vs_reference_golden(cuda):
     assert_close(theta, g["theta"], atol=2e-5, what="theta")
     # The TPS map is evaluated in fp64 and rounded once (exact on a given theta, tests/test_ops_gpu.py::test_tps_grid); the grid
     # difference to the reference is its ~3.7x amplification of the theta difference (9.4e-6 measured here: two fp32
-    # evaluations of 16 layers, each ~5e-6 from the exact value): 2.0e-5 measured.
+    # evaluations of 16 layers, each ~5e-6 from the exact value): 2.0e-5 measured.  DEVIATION from SURVEY.md 0-6, which quotes
+    # 1e-5 for the model-level grid: two independent fp32 evaluations of this 16-layer graph cannot agree to 1e-5 on theta
+    # x 3.7; the 1e-5 bar is kept where it can hold - the grid on a GIVEN theta (2.5e-7, test_tps_grid) and the fp64 leg below.
     assert_close(strided(grid.permute(0, 3, 1, 2)), g["grid_s8"], atol=3e-5, what="grid")
     # warped cloth: bilinear sampling amplifies the grid difference by the image slope (~5 per unit of normalised coordinate
     # for the band-limited fixture): 1.2e-4 at 3 of the 4608 REFERENCE samples.  The north-star 1e-4 is therefore stated the
