@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void linear_chw_bwd_x_k(const float* __restric
     const unsigned b = idx / K, t = idx - b * K;
     const unsigned p = t / C, c = t - p * C;
     float s = 0.f;
-    for (unsigned j = 0; j < J; ++j) {
+#pragma unroll 10
+    for (unsigned j = 0; j < J; ++j) {   // (unrolled: ten rows' loads in flight per round; the sum keeps its order)
       const float yv = y[(size_t)b * J + j];
       const float dz = dy[(size_t)b * J + j] * (apply_tanh ? (1.f - yv * yv) : 1.f);
       s += dz * w[(size_t)j * K + c * P + p];

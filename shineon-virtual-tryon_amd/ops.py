@@ -316,7 +316,7 @@ class _Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0,
-                bias_grad_hint=False):
+                bias_grad_hint=False, forward_only=False):
         L = lib()
         ctx.bias_hint = bool(bias_grad_hint)
         if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
@@ -342,7 +342,12 @@ class _Conv2dFn(torch.autograd.Function):
                                                   n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
         if wino != "direct":
             # 3x3 / s1 / p1 (U-Net up path, SPADE): Winograd F(2x2,3x3); trainable weights are transformed per call
-            u = _wino_weights(w, None, False, fused=wino == "fused", ko_pad=op, f44=wino == "nonfused4")
+            # forward only on a stand-alone parameter (inference: every update goes through torch and bumps its version): the
+            # Winograd-domain weights are cached like the frozen VGG's; parameters planted in an optimizer's slab are updated
+            # through raw pointers, so they - and every pass that needs gradients - are transformed per call
+            owner = ((weakref.ref(weight), weight._version)
+                     if forward_only and weight.untyped_storage().nbytes() == weight.numel() * 4 else None)
+            u = _wino_weights(w, owner, False, fused=wino == "fused", ko_pad=op, f44=wino == "nonfused4")
             wino_conv3x3(xr.data_ptr(), _ld(xr), u, bias, None, y.data_ptr(), op, n, h, wd, cp, op, act, x.device,
                          fused=wino == "fused", act_param=act_param, f44=wino == "nonfused4")
         else:
@@ -469,7 +474,7 @@ class _Conv2dFn(torch.autograd.Function):
         if need_w or need_b:
             dw, db = weight_grads(lane=0)
         grad_ready(w_direct, b_direct)   # both the input- and the weight-gradient kernels of this layer are in the stream
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False,
@@ -478,7 +483,14 @@ def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_gr
     output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
     act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
     (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel."""
-    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param, bias_grad_hint)
+    return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param, bias_grad_hint,
+                           _forward_only(x, weight, bias))
+
+
+def _forward_only(*ts):
+    """True when no gradient can be asked of this call (grad mode off, or nothing requires grad).  Inside an
+    autograd.Function's forward grad mode is always off and needs_input_grad follows requires_grad, so the wrappers decide."""
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -870,6 +882,37 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+_QKV_CACHE = {}
+
+
+def _stacked_qkv(wq, bq, wk, bk, wv, bv):
+    """([Wq; Wk; Wv] as one [2d + C][C] matrix, [bq; bk; bv]) for a forward pass that needs no gradients, or None.  The three
+    1x1 projections then run as ONE GEMM (4 launches fewer per module; each costs >= 4 us inside a replayed graph).  Copies are
+    cached per parameter objects and versions.  Parameters that are views of a larger storage (planted in an optimizer's flat
+    slab, which is updated through raw pointers without a version bump) are never cached: adjacent ones are used in place,
+    others take the three-GEMM path."""
+    ws_, bs_ = (wq, wk, wv), (bq, bk, bv)
+    if any(t.shape[0] % 4 for t in ws_):
+        return None
+    if _adjacent(ws_) and _adjacent(bs_) and all(t.dim() != 4 or t.permute(0, 2, 3, 1).is_contiguous() for t in ws_):
+        return wq, bq
+    if any(t.untyped_storage().nbytes() != t.numel() * 4 for t in ws_ + bs_):
+        return None
+    key = tuple(id(t) for t in ws_ + bs_)
+    ver = tuple(t._version for t in ws_ + bs_)
+    hit = _QKV_CACHE.get(key)
+    if hit is not None and all(r() is t for r, t in zip(hit[0], ws_ + bs_)) and hit[1] == ver:
+        return hit[2], hit[3]
+    c = wq.shape[1]
+    with torch.no_grad():
+        wcat = torch.cat([_ohwi(t).reshape(t.shape[0], c) for t in ws_], 0).contiguous()
+        bcat = torch.cat([t.detach() for t in bs_], 0).contiguous()
+    for k in [k for k, v in _QKV_CACHE.items() if any(r() is None for r in v[0])]:
+        del _QKV_CACHE[k]
+    _QKV_CACHE[key] = (tuple(weakref.ref(t) for t in ws_ + bs_), ver, wcat, bcat)
+    return wcat, bcat
+
+
 class _SelfAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
@@ -972,7 +1015,32 @@ class _SelfAttentionFn(torch.autograd.Function):
         return (dx, dwq[:d_true].view(sq), dbq[:d_true], dwk[:d_true].view(sk), dbk[:d_true], dwv.view(sv), dbv, dgamma)
 
 
+@torch.no_grad()
+def _self_attention_forward_only(x, wcat, bcat, gamma, d):
+    """q | k | v = column slices of ONE projection GEMM (as _SelfAttentionQkvFn.forward), nothing saved."""
+    L = lib()
+    x = _dense_rows(x)
+    b, c, h, w = x.shape
+    n, E, dev = h * w, 2 * d + c, x.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    ldx, xp = _ld(x), x.data_ptr()
+    qkv = f(b * n, E)
+    _gemm(0, 1, b * n, E, c, xp, ldx, 0, wcat.data_ptr(), c, 0, qkv.data_ptr(), E, 0, 1, bias=bcat.data_ptr(), device=dev)
+    qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
+    e, a, o = f(b * n, n), f(b * n, n), f(b * n, c)
+    out = nhwc_empty(b, h, w, c, dev)
+    _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
+    check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
+    _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
+    check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
+    return out
+
+
 def self_attention(x, wq, bq, wk, bk, wv, bv, gamma):
+    if x.is_cuda and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and _forward_only(x, wq, bq, wk, bk, wv, bv, gamma):
+        stacked = _stacked_qkv(wq, bq, wk, bk, wv, bv)
+        if stacked is not None:
+            return _self_attention_forward_only(x, stacked[0], stacked[1], gamma, wq.shape[0])
     ws_, bs_ = (wq, wk, wv), (bq, bk, bv)
     fused = (x.is_cuda and wq.shape[0] % 4 == 0 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
              and all(_direct_grad_ok(t, ohwi=True) for t in ws_) and all(_direct_grad_ok(t, ohwi=False) for t in bs_)

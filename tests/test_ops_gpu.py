@@ -325,6 +325,17 @@ def test_self_attention(ops, cuda, hw):
 
     compare_fwd_bwd(ops.self_attention, ref, [(t, True) for t in (x, wq, bq, wk, bk, wv, bv, gamma)], cuda,
                     atol=2e-5, gatol=1e-4, what=f"self_attention {hw}")
+    # forward only (no gradient asked for): the three projections run as one GEMM on a cached [Wq; Wk; Wv] - same result, and
+    # the cache follows the parameters (an in-place update bumps the version; a new tensor is a new entry)
+    dev_in = [t.to(cuda) for t in (x, wq, bq, wk, bk, wv, bv, gamma)]
+    with torch.no_grad():
+        want = ref(x, wq, bq, wk, bk, wv, bv, gamma)
+        for _ in range(2):   # second call: cache hit
+            assert_close(ops.self_attention(*dev_in), want, atol=2e-5, what=f"self_attention forward-only {hw}")
+        assert ops._QKV_CACHE, "the forward-only path did not run"
+        dev_in[5].mul_(1.5)
+        assert_close(ops.self_attention(*dev_in), ref(x, wq, bq, wk, bk, wv * 1.5, bv, gamma), atol=3e-5,
+                     what=f"self_attention forward-only after an in-place weight update {hw}")
 
 
 # ------------------------------------------------------------------------------------------------ GMM
