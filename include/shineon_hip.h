@@ -112,6 +112,12 @@ long long so_wino_fused_weight_floats(int Ko, int C, int flip_transpose);
 int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int flip_transpose, void* stream);
 int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream);
+/* The same convolution followed by nn.MaxPool2d(2, 2) (models/networks/vgg.py:14-25: conv1_2 -> pool, conv2_2 -> pool): an
+ * F(2x2) output tile is one pooling window, so the epilogue also writes ypool [Nb][H/2][W/2][ldyp] (H, W even); y itself is
+ * stored for the first n_keep images only (y may be NULL when n_keep = 0). */
+int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const float* bias, int nbias, float* y, int ldy,
+                               int n_keep, float* ypool, int ldyp, int Nb, int H, int W, int C, int Ko, int act,
+                               float act_param, void* stream);
 /* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);

@@ -197,8 +197,10 @@ struct WinoP {
   const float* bias;
   const float* gate;
   float* y;
+  float* yp;           // optional: max over each 2x2 output tile (= nn.MaxPool2d(2, 2) of y: an F(2x2) tile is one pooling window)
   unsigned x_bytes, u_bytes;
   int ldx, ldy, Nb, H, W, C, Ko, nbias, pbx, pby, nkb, nks, act;
+  int ldyp, n_keep;    // images >= n_keep do not store y at all (their un-pooled activations are never read)
   float act_param;
 };
 
@@ -598,6 +600,8 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
       }
       // the convolutions that reach this kernel fuse no activation, ReLU or LeakyReLU only (ops.conv2d): one select
       const float slope = p.act == SO_ACT_RELU ? 0.f : (p.act == SO_ACT_LEAKY ? p.act_param : 1.f);
+      f32x4 vmax;
+      const bool keep = n < p.n_keep;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int h = 2 * ty + a;
@@ -614,10 +618,18 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = g[q] > 0.f ? v[q] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(p.y + off) = v;
+            if (keep) *reinterpret_cast<f32x4*>(p.y + off) = v;
+            if (a == 0 && b == 0) vmax = v;
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) vmax[q] = fmaxf(vmax[q], v[q]);
+            }
           }
         }
       }
+      // pooled output (launcher: H and W even, so a tile is inside the image entirely or not at all)
+      if (p.yp && 2 * ty < p.H && 2 * tx < p.W)
+        *reinterpret_cast<f32x4*>(p.yp + ((long long)(n * (p.H >> 1) + ty) * (p.W >> 1) + tx) * p.ldyp + ko) = vmax;
     }
   }
 }
@@ -953,8 +965,27 @@ void so_wino_fused_dma(int on) { g_wino_dma = on; }   // 1 (default): LDS-DMA st
 //  (conv1_2 176 vs 162 us, conv2_2 150 vs 131 us, step 576 vs 589 frames/s: 2x the patch loads, 5 instead of 1.4 loads per
 //  lane and step, spills at 168 VGPRs), i.e. the per-step barrier is not what holds the kernel at 53 % of the pipe.  Removed.)
 
+static int wino_fused_launch(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                             int ldy, float* ypool, int ldyp, int n_keep, int Nb, int H, int W, int C, int Ko, int act,
+                             float act_param, void* stream);
+
 int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
                           int ldy, int Nb, int H, int W, int C, int Ko, int act, float act_param, void* stream) {
+  return wino_fused_launch(x, ldx, U, bias, nbias, gate, y, ldy, nullptr, 0, Nb, Nb, H, W, C, Ko, act, act_param, stream);
+}
+
+// The same convolution with nn.MaxPool2d(2, 2) of its output written by the epilogue (ypool: [Nb][H/2][W/2][ldyp]); y itself is
+// stored for the first n_keep images only (VGG19 on [prediction | target]: the target's un-pooled activations are never read).
+int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const float* bias, int nbias, float* y, int ldy,
+                               int n_keep, float* ypool, int ldyp, int Nb, int H, int W, int C, int Ko, int act,
+                               float act_param, void* stream) {
+  if (!ypool || (H & 1) || (W & 1) || (ldyp & 3) || (((uintptr_t)ypool) & 15) || n_keep < 0 || n_keep > Nb) return SO_ERR_SHAPE;
+  return wino_fused_launch(x, ldx, U, bias, nbias, nullptr, y, ldy, ypool, ldyp, n_keep, Nb, H, W, C, Ko, act, act_param, stream);
+}
+
+static int wino_fused_launch(const float* x, int ldx, const float* U, const float* bias, int nbias, const float* gate, float* y,
+                             int ldy, float* ypool, int ldyp, int n_keep, int Nb, int H, int W, int C, int Ko, int act,
+                             float act_param, void* stream) {
   if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 15) || (((uintptr_t)U) & 15) ||
       (gate && (((uintptr_t)gate) & 15)))
     return SO_ERR_ALIGN;
@@ -963,6 +994,7 @@ int so_wino_fused_conv3x3(const float* x, int ldx, const float* U, const float* 
   if (xb <= 0 || xb >= 0x7FFFFFF0LL || ub >= 0x7FFFFFF0LL) return SO_ERR_SHAPE;
   WinoP p = {};
   p.x = x; p.U = U; p.bias = bias; p.gate = gate; p.y = y;
+  p.yp = ypool; p.ldyp = ldyp; p.n_keep = n_keep;
   p.x_bytes = (unsigned)xb; p.u_bytes = (unsigned)ub;
   p.ldx = ldx; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.C = C; p.Ko = Ko; p.nbias = nbias;
   p.pbx = ((W + 1) / 2 + 7) / 8; p.pby = ((H + 1) / 2 + 3) / 4;

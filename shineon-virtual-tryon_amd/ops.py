@@ -1635,8 +1635,12 @@ class _VggLossFn(torch.autograd.Function):
         relu_in = None  # index in `saved` of the ReLU output that is the current tensor (None: image / pooled map)
         split = VGG_SPLIT_BF16
         planes = None   # (hi, mid) bf16 planes of `cur` when the producing convolution emitted them
+        skip_pool = False
         for ii, item in enumerate(cfg):
             n2, ci, hh, ww = cur.shape
+            if item[0] == "M" and skip_pool:   # written by the preceding convolution's epilogue (below)
+                skip_pool = False
+                continue
             if item[0] == "M":
                 planes = None
                 out = nhwc_empty(n2, hh // 2, ww // 2, ci, dev)
@@ -1667,6 +1671,23 @@ class _VggLossFn(torch.autograd.Function):
                 elif _wino_mode(ci, co, n2, hh, ww) != "direct":
                     wm = _wino_mode(ci, co, n2, hh, ww)
                     fz, f4 = wm == "fused", wm == "nonfused4"
+                    nxt = cfg[ii + 1] if ii + 1 < len(cfg) else None
+                    if fz and item[1] is None and nxt is not None and nxt[0] == "M" and hh % 2 == 0 and ww % 2 == 0:
+                        # conv -> ReLU -> MaxPool2d(2, 2) (vgg.py: conv1_2, conv2_2): an F(2x2) output tile IS a pooling window,
+                        # so the epilogue writes the pooled map too, and the un-pooled activations only of the prediction
+                        # half (the backward pass gates on them; nobody reads the target's)
+                        out = nhwc_empty(b, hh, ww, co, dev)
+                        pooled = nhwc_empty(n2, hh // 2, ww // 2, co, dev)
+                        u = _wino_weights(wk, wowner, False, True)
+                        check(L.so_wino_fused_conv3x3_pool(cur.data_ptr(), ci, u.data_ptr(), bias.data_ptr(), bias.numel(), out.data_ptr(),
+                                                           co, b, pooled.data_ptr(), co, n2, hh, ww, ci, co, ACT_RELU, 0.0, _stream()),
+                              "wino_fused_conv3x3_pool")
+                        saved.extend([out, wk])
+                        meta.append(("C", len(saved) - 2, len(saved) - 1, None, ci, (weakref.ref(weight), weight._version), relu_in, None))
+                        saved.append(out)
+                        meta.append(("M", len(saved) - 1, True))
+                        relu_in, planes, cur, skip_pool = None, None, pooled, True
+                        continue
                     wino_conv3x3(cur.data_ptr(), ci, _wino_weights(wk, wowner, False, fz, f44=f4), bias, None, out.data_ptr(), co, n2,
                                  hh, ww, ci, co, ACT_RELU, dev, fused=fz, f44=f4)
                     planes = None

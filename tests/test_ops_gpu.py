@@ -564,6 +564,19 @@ def test_winograd_conv3x3_matches_fp64_convolution(cuda, ops, n, h, w, c, ko, ac
     e_f = float((y2.cpu().double() - ref).abs().max())
     print(f"   fused: max err {e_f:.2e}")
     assert e_f <= 4 * e_d + 2e-6 * big, (e_f, e_d, big)
+    if not gated and h % 2 == 0 and w % 2 == 0:
+        # ... with MaxPool2d(2, 2) written by the epilogue: the pooled map is bit-identical to pooling y2, y itself is stored
+        # for the first n_keep images only (the rest of the buffer is never touched)
+        for n_keep in sorted({n, n // 2, 0}):
+            y3 = torch.full((n, h, w, ko), float("nan"), device=cuda)
+            yp = torch.full((n, h // 2, w // 2, ko), float("nan"), device=cuda)
+            assert L.so_wino_fused_conv3x3_pool(xd.data_ptr(), c, uf.data_ptr(), bd.data_ptr(), ko, y3.data_ptr(), ko, n_keep,
+                                                yp.data_ptr(), ko, n, h, w, c, ko, act, 0.0, st) == 0
+            want = F.max_pool2d(y2.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+            assert torch.equal(yp, want), ("pooled epilogue", n_keep)
+            assert torch.equal(y3[:n_keep], y2[:n_keep]) and bool(torch.isnan(y3[n_keep:]).all()), ("n_keep", n_keep)
+        assert L.so_wino_fused_conv3x3_pool(xd.data_ptr(), c, uf.data_ptr(), bd.data_ptr(), ko, y3.data_ptr(), ko, n, None, ko, n, h, w,
+                                            c, ko, act, 0.0, st) != 0, "a missing pooled output must be refused"
     # F(4x4, 3x3) (36 transform points, the deep layers): its fp32 round-off is of the order of the direct K = 9C MFMA chain's
     u4 = torch.empty(36, ko, c, device=cuda)
     assert L.so_wino4_weights(wd.data_ptr(), u4.data_ptr(), ko, ko, c, 0, st) == 0
