@@ -179,6 +179,11 @@ long long so_norm_ws_floats(int G, long long R, int C);
 int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
                 const float* gamma, const float* beta, float* mean, float* rstd,
                 float* running_mean, float* running_var, float momentum, float* ws, void* stream);
+/* so_norm_fwd with a second output y2 = act(y) from the same launch: the activation that the consumer applies first (the
+ * U-Net's [norm] -> submodule [GELU -> conv], models/networks/cpvton/unet.py:132-147) while y itself stays for the skip path */
+int so_norm_act_fwd(const float* x, int ldx, float* y, int ldy, float* y2, int ldy2, int act, float act_param, int G,
+                    long long R, int C, float eps, const float* gamma, const float* beta, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum, float* ws, void* stream);
 
 /* BatchNorm2d in eval mode (test_step): statistics are inputs; stat_is_var = 1 -> `stat` is a variance. */
 int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R, int C,

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
                                                     const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int stat_is_var,
-                                                    float eps) {
+                                                    float eps, float* __restrict__ y2, int ldy2, int act2,
+                                                    float act2_param) {
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
@@ -152,6 +153,12 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
       o[i] = v;
     }
     *reinterpret_cast<vec_t*>(y + (size_t)row * ldy + c0) = o;
+    if (y2) {   // the consumer's activation of the same values (so_norm_act_fwd): second output, same launch
+      vec_t o2;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o2[i] = so_actf(act2, o[i], act2_param);
+      *reinterpret_cast<vec_t*>(y2 + (size_t)row * ldy2 + c0) = o2;
+    }
   }
 }
 
@@ -277,7 +284,8 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* __restrict__ running_mean,
-                                                         float* __restrict__ running_var, float momentum) {
+                                                         float* __restrict__ running_var, float momentum,
+                                                         float* __restrict__ y2, int ldy2, int act2, float act2_param) {
   __shared__ float sn[32][33], sm[32][33], s2[32][33];
   __shared__ float bmean[32], brstd[32];
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
     float v = (bx[(size_t)r * ldx] - m) * rs;
     if (gamma) v = v * ga + be;
     by[(size_t)r * ldy] = v;
+    if (y2) y2[((size_t)g * R + r) * ldy2 + col] = so_actf(act2, v, act2_param);
   }
 }
 
@@ -421,15 +430,15 @@ long long so_norm_ws_floats(int G, long long R, int C) {
 }
 
 // Training-mode statistics + normalisation.  mean/rstd: [G][C] outputs (saved for backward).
-int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
-                const float* gamma, const float* beta, float* mean, float* rstd,
-                float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
+static int norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* y2, int ldy2, int act2, float act2_param, int G,
+                           long long R, int C, float eps, const float* gamma, const float* beta, float* mean, float* rstd,
+                           float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
   if (running_mean && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (R <= kSmallRows) {
     hipLaunchKernelGGL(norm_small_fwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, y, ldy, (unsigned)R,
-                       (unsigned)C, eps, gamma, beta, mean, rstd, running_mean, running_var, momentum);
+                       (unsigned)C, eps, gamma, beta, mean, rstd, running_mean, running_var, momentum, y2, ldy2, act2, act2_param);
     return SO_LAUNCH_CHECK();
   }
   unsigned chunk, nchunk;
@@ -443,13 +452,30 @@ int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, 
                      running_mean, running_var, momentum);
   if (!y) return SO_LAUNCH_CHECK();  // statistics only: the caller normalises inside its own pass (so_spade_norm_fwd)
   const long long total = (long long)G * R * C;
-  if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && al16(x) && al16(y) && al16(mean) && al16(rstd))
+  if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && al16(x) && al16(y) && al16(mean) && al16(rstd) &&
+      (!y2 || ((ldy2 & 3) == 0 && al16(y2))))
     hipLaunchKernelGGL(norm_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps);
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param);
   else
     hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps);
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param);
   return SO_LAUNCH_CHECK();
+}
+
+int so_norm_fwd(const float* x, int ldx, float* y, int ldy, int G, long long R, int C, float eps,
+                const float* gamma, const float* beta, float* mean, float* rstd,
+                float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
+  return norm_fwd_launch(x, ldx, y, ldy, nullptr, 0, 0, 0.f, G, R, C, eps, gamma, beta, mean, rstd, running_mean, running_var,
+                         momentum, ws, stream);
+}
+
+// so_norm_fwd with a second output y2 = act(y) written by the same launch (the activation the consumer applies first)
+int so_norm_act_fwd(const float* x, int ldx, float* y, int ldy, float* y2, int ldy2, int act, float act_param, int G,
+                    long long R, int C, float eps, const float* gamma, const float* beta, float* mean, float* rstd,
+                    float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
+  if (!y || !y2) return SO_ERR_SHAPE;
+  return norm_fwd_launch(x, ldx, y, ldy, y2, ldy2, act, act_param, G, R, C, eps, gamma, beta, mean, rstd, running_mean,
+                         running_var, momentum, ws, stream);
 }
 
 // Inference-mode normalisation with given statistics (BatchNorm eval: mean = running_mean,
@@ -461,7 +487,7 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
   const long long total = (long long)G * R * C;
   hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      y, ldy, (unsigned)G, (unsigned)R, (unsigned)C, mean, stat, gamma, beta,
-                     stat_is_var, eps);
+                     stat_is_var, eps, (float*)nullptr, 0, 0, 0.f);
   return SO_LAUNCH_CHECK();
 }
 

@@ -100,16 +100,26 @@ class UnetSkipConnectionBlock(nn.Module):
         out = self.forward_pair(x)
         return out.cat() if isinstance(out, SkipPair) else out
 
-    def forward_pair(self, x):
+    def forward_pair(self, x, preact=None):
         """forward() with the skip concatenation [x | h] left as a SkipPair: the enclosing block's `act -> Upsample` reads
-        both parts directly (ops.upsample2x_bilinear_cat), so torch.cat's copy never happens on the hot path."""
+        both parts directly (ops.upsample2x_bilinear_cat), so torch.cat's copy never happens on the hot path.
+        preact: this block's down activation of x, already computed by the producer of x (_run: norm -> block)."""
         if self.outermost:
             return _run(list(self.model), x)
         mods = list(self.model)
         if self.skip_carries_activation:
             x = mods[0](x)
             mods = mods[1:]
+        elif preact is not None:
+            return SkipPair(x, _run(mods[1:], preact))
         return SkipPair(x, _run(mods, x))
+
+    def takes_preactivation(self):
+        """The down activation (first module) is a plain, not-in-place activation of the block input: its value can come from
+        the kernel that produces the input."""
+        first = self.model[0]
+        return (not self.outermost and not self.skip_carries_activation and isinstance(first, HipActivation)
+                and first.kind in ops.ACT_CODES)
 
 
 class SkipPair:
@@ -135,6 +145,13 @@ def _run(mods, h):
                 h = ops.upsample2x_bilinear_cat(h.x, h.h, m.kind, m.param)
             else:
                 h = ops.upsample2x_bilinear(h, m.kind, m.param)
+            i += 2
+        elif (isinstance(m, HipInstanceNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], UnetSkipConnectionBlock)
+              and mods[i + 1].takes_preactivation() and not isinstance(h, SkipPair) and h.is_cuda):
+            # norm -> [submodule: act -> conv ...]: the norm kernel writes act(y) beside y (y stays for the skip connection)
+            nxt = mods[i + 1]
+            y, a = ops.instance_norm_act(h, m.eps, nxt.model[0].kind, nxt.model[0].param)
+            h = nxt.forward_pair(y, preact=a)
             i += 2
         else:
             if isinstance(h, SkipPair):

@@ -551,17 +551,22 @@ class _CatFn(torch.autograd.Function):
         n, _, h, w = xs[0].shape
         cs = [x.shape[1] for x in xs]
         ct = sum(cs)
-        out = nhwc_empty(n, h, w, ct, xs[0].device)
+        # the slab's pitch is rounded up to a multiple of 4 and the pad columns are ZERO (written by the last source's kernel):
+        # a convolution that needs its input channels padded (ops.conv2d: 16-byte loaders) reads the slab in place instead of
+        # copying it into a padded buffer first (cat_channels marks the result `_so_zero_padded`)
+        ld = (ct + 3) // 4 * 4
+        out = nhwc_empty(n, h, w, ct, xs[0].device, ld=ld)
         off = 0
-        for x, c in zip(xs, cs):
+        for k, (x, c) in enumerate(zip(xs, cs)):
             _require_cuda(x)
             if x.dtype != torch.float32:
                 raise TypeError("fp32 only")
+            cd = c + (ld - ct if k == len(xs) - 1 else 0)   # the last source also writes the pad columns (zeros)
             if _is_rows(x):
-                check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * off, ct, c, n * h * w, 0, _stream()), "copy2d")
+                check(L.so_copy2d(x.data_ptr(), _ld(x), c, out.data_ptr() + 4 * off, ld, cd, n * h * w, 0, _stream()), "copy2d")
             else:   # planar (batch tensors): transposed straight into its channel range, no private NHWC copy first
                 src = x if x.is_contiguous() else x.contiguous()
-                check(L.so_nchw_to_nhwc(src.data_ptr(), out.data_ptr() + 4 * off, ct, n, c, c, h * w, _stream()), "nchw_to_nhwc")
+                check(L.so_nchw_to_nhwc(src.data_ptr(), out.data_ptr() + 4 * off, ld, n, c, cd, h * w, _stream()), "nchw_to_nhwc")
             off += c
         ctx.cs = cs
         return out
@@ -578,7 +583,10 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(xs):
     """torch.cat(xs, dim=1) for NHWC-pitch tensors (gradient = channel slices, no copy)."""
-    return _CatFn.apply(*xs)
+    y = _CatFn.apply(*xs)
+    if _is_rows(y) and _ld(y) != y.shape[1]:
+        y._so_zero_padded = _ld(y)   # pitch = channels rounded up to 4, pad columns zero (see _CatFn.forward)
+    return y
 
 
 class _CatBatchFn(torch.autograd.Function):
@@ -710,34 +718,40 @@ class _NormFn(torch.autograd.Function):
     """InstanceNorm2d (instance=True) or BatchNorm2d training (instance=False)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps, relu_gate_input=False):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps, relu_gate_input=False, act2=None,
+                act2_param=0.0):
+        """act2 (an activation code): also return act2(y), written by the same launch - the consumer's first operation; that
+        second output carries no gradient here (ops.instance_norm_act hangs the activation's own backward node on it)."""
         L = lib()
         x = to_rows(x)
         n, c, h, w = x.shape
         G, R = (n, h * w) if instance else (1, n * h * w)
         y = nhwc_empty(n, h, w, c, x.device)
+        a = nhwc_empty(n, h, w, c, x.device) if act2 is not None else None
         mean = torch.empty((G, c), dtype=torch.float32, device=x.device)
         rstd = torch.empty((G, c), dtype=torch.float32, device=x.device)
         ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
-        check(
-            L.so_norm_fwd(
-                x.data_ptr(), _ld(x), y.data_ptr(), c, G, R, c, eps,
-                gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None,
+        tail = (eps, gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None,
                 mean.data_ptr(), rstd.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None,
-                momentum, ws.data_ptr(), _stream(),
-            ),
-            "norm_fwd",
-        )
+                momentum, ws.data_ptr(), _stream())
+        if a is None:
+            check(L.so_norm_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, G, R, c, *tail), "norm_fwd")
+        else:
+            check(L.so_norm_act_fwd(x.data_ptr(), _ld(x), y.data_ptr(), c, a.data_ptr(), c, int(act2), float(act2_param), G, R, c,
+                                    *tail), "norm_act_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma)
         ctx.cfg = (G, R, bool(relu_gate_input))
         # affine parameters living in the optimizer's flat slab get their gradients accumulated in place
         ctx.direct = (gamma, beta) if gamma is not None and _direct_grad_ok(gamma, False) and _direct_grad_ok(beta, False) else None
-        return y
+        if a is None:
+            return y
+        ctx.mark_non_differentiable(a)
+        return y, a
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _da=None):
         L = lib()
         x, mean, rstd, gamma = ctx.saved_tensors
         G, R, relu_gate = ctx.cfg
@@ -763,11 +777,34 @@ class _NormFn(torch.autograd.Function):
         )
         if ctx.direct is not None:
             grad_ready(*ctx.direct)
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def instance_norm(x, eps=1e-5):
     return _NormFn.apply(x, None, None, None, None, True, 0.0, eps)
+
+
+class _PrecomputedActFn(torch.autograd.Function):
+    """act(x) whose VALUE was already written by the kernel that produced x (so_norm_act_fwd): the forward launches nothing,
+    the backward is _ActFn's - so the autograd graph, its kernels and its bits are those of `activation(x)`."""
+
+    @staticmethod
+    def forward(ctx, x, a, act, param):
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, param)
+        return a.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ActFn.backward(ctx, dy) + (None,)
+
+
+def instance_norm_act(x, eps, kind, param=0.0):
+    """(y, act(y)) with y = instance_norm(x): one launch for both - the U-Net hands y to the skip connection and act(y) to
+    the next block's convolution (models/networks/cpvton/unet.py:132-147, 187)."""
+    code = ACT_CODES[kind] if not isinstance(kind, int) else kind
+    y, a = _NormFn.apply(x, None, None, None, None, True, 0.0, eps, False, code, float(param))
+    return y, _PrecomputedActFn.apply(y, a, code, float(param))
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu_gate_input=False):

@@ -206,6 +206,23 @@ def test_instance_norm(ops, cuda):
                         gatol=5e-5, what=f"instance_norm {shape}")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16, 12), (2, 128, 64, 48), (1, 8, 5, 7)])
+@pytest.mark.parametrize("kind", ["gelu", "leaky"])
+def test_instance_norm_with_the_consumers_activation_is_bit_identical(ops, cuda, shape, kind):
+    """ops.instance_norm_act: (y, act(y)) from ONE launch - values and gradients bit-identical to instance_norm followed by
+    activation (the activation's backward node is the same kernel; only its forward launch is gone)."""
+    x = rnd(*shape, seed=71).to(cuda)
+    gy, ga = rnd(*shape, seed=72).to(cuda), rnd(*shape, seed=73).to(cuda)
+    x1 = x.clone().requires_grad_(True)
+    y1 = ops.instance_norm(x1, 1e-5)
+    a1 = ops.activation(y1, kind, 0.2)
+    (g1,) = torch.autograd.grad((y1 * gy).sum() + (a1 * ga).sum(), x1)
+    x2 = x.clone().requires_grad_(True)
+    y2, a2 = ops.instance_norm_act(x2, 1e-5, kind, 0.2)
+    (g2,) = torch.autograd.grad((y2 * gy).sum() + (a2 * ga).sum(), x2)
+    assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(g1, g2)
+
+
 def test_instance_norm_known_answer(ops, cuda):
     y = ops.instance_norm(rnd(2, 8, 32, 24, seed=13).to(cuda) * 5 + 1)
     yc = ops.to_nchw(y).cpu()
@@ -453,7 +470,15 @@ def test_cat_channels_takes_planar_sources_straight_into_the_slab(ops, cuda):
     rows = ops.activation(b, None)   # an NHWC-pitch tensor among planar ones
     out = ops.cat_channels([a, rows, c])
     assert torch.equal(out, torch.cat([a, b, c], 1))
-    assert out.permute(0, 2, 3, 1).is_contiguous()
+    # 26 channels: the slab's pitch is 28 and the two pad columns are zero, so a convolution reads it in place
+    assert ops._is_rows(out) and ops._ld(out) == 28 and getattr(out, "_so_zero_padded", 0) == 28
+    padded = torch.as_strided(out, (2, 28, 32, 24), out.stride(), out.storage_offset())
+    assert float(padded[:, 26:].abs().max()) == 0.0
+    w = rnd(8, 26, 3, 3, seed=66, scale=0.1).to(cuda)
+    assert_close(ops.conv2d(out, w, None, 1, 1), F.conv2d(torch.cat([a, b, c], 1).cpu(), w.cpu(), None, 1, 1), atol=2e-5,
+                 what="conv on the zero-padded concatenation")
+    out4 = ops.cat_channels([a, a[:, :2].contiguous()])   # 24 channels: dense
+    assert ops._ld(out4) == 24 and out4.permute(0, 2, 3, 1).is_contiguous() and torch.equal(out4, torch.cat([a, a[:, :2]], 1))
 
 
 def test_tryon_compose_and_blend(ops, cuda):
