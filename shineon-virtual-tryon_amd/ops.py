@@ -1064,12 +1064,13 @@ def _self_attention_forward_only(x, wcat, bcat, gamma, d):
     qkv = f(b * n, E)
     _gemm(0, 1, b * n, E, c, xp, ldx, 0, wcat.data_ptr(), c, 0, qkv.data_ptr(), E, 0, 1, bias=bcat.data_ptr(), device=dev)
     qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
-    e, a, o = f(b * n, n), f(b * n, n), f(b * n, c)
+    e, a = f(b * n, n), f(b * n, n)
     out = nhwc_empty(b, h, w, c, dev)
     _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
     check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
-    _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, o.data_ptr(), c, n * c, b, device=dev)
-    check(L.so_scale_add(o.data_ptr(), c, gamma.data_ptr(), xp, ldx, out.data_ptr(), c, b * n, c, _stream()), "scale_add")
+    # gamma * (attention x V) + x in the product's epilogue (alpha, residual): o itself is only needed by d gamma
+    _gemm(0, 0, n, c, n, a.data_ptr(), n, n * n, vp, E, n * E, out.data_ptr(), c, n * c, b, alpha=gamma.data_ptr(), res=xp,
+          ldres=ldx, sres=n * ldx, device=dev)
     return out
 
 
