@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void wino_weights_k(const float* __restrict__ 
                                                       int Kw, int flip_transpose) {
   const long long total = (long long)Ko * C;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int ko = (int)(idx / C), c = (int)(idx - (long long)ko * C);
+    int ko, c;   // consecutive threads = consecutive elements of the OUTPUT row (see wino4_weights_k)
+    if (flip_transpose) { c = (int)(idx / Ko); ko = (int)(idx - (long long)c * Ko); }
+    else { ko = (int)(idx / C); c = (int)(idx - (long long)ko * C); }
     float g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -807,7 +809,11 @@ __global__ __launch_bounds__(256) void wino4_weights_k(const float* __restrict__
                                                        int Kw, int flip_transpose) {
   const long long total = (long long)Ko * C;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int ko = (int)(idx / C), c = (int)(idx - (long long)ko * C);
+    // consecutive threads follow the OUTPUT's fastest index (c forward, ko for the transposed U'): the 36 stores of a thread
+    // are then 36 coalesced rows; the transposed form pays with 9 strided loads instead (it used to pay with 36 strided stores)
+    int ko, c;
+    if (flip_transpose) { c = (int)(idx / Ko); ko = (int)(idx - (long long)c * Ko); }
+    else { ko = (int)(idx / C); c = (int)(idx - (long long)ko * C); }
     float g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
