@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void linear_chw_bwd_x_k(const float* __restric
   const unsigned K = P * C;
   const unsigned total = Nb * K;
   for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    // consecutive threads = consecutive p of one channel: the J weight rows are read along their contiguous (c * P + p) axis
+    // (with c fastest every one of the J loads of a thread was a 4-byte access at a P-float stride); the single store pays
     const unsigned b = idx / K, t = idx - b * K;
-    const unsigned p = t / C, c = t - p * C;
+    const unsigned c = t / P, p = t - c * P;
     float s = 0.f;
 #pragma unroll 10
     for (unsigned j = 0; j < J; ++j) {   // (unrolled: ten rows' loads in flight per round; the sum keeps its order)
