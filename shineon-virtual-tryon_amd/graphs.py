@@ -31,6 +31,9 @@ class GraphedTrainStep:
         self.static_batch = {k: (v.clone() if isinstance(v, torch.Tensor) and k not in alias_keys else v)
                              for k, v in sample_batch.items()}
         self.alias_keys = tuple(alias_keys)
+        # only the entries the model reads are refreshed per step (the dataset's batches carry 13 tensors, a model reads ~5;
+        # each copy is a launch of its own in front of the graph)
+        self.keys = model.batch_keys() if hasattr(model, "batch_keys") else None
         self.result = None
         # trainer.BucketedExchange: its counter bump and "bucket ready" signal kernels are recorded INSIDE the graph, at the
         # points of the backward pass where each gradient bucket is complete
@@ -68,6 +71,8 @@ class GraphedTrainStep:
             if k in self.alias_keys:
                 continue
             if isinstance(v, torch.Tensor):
+                if self.keys is not None and k not in self.keys:
+                    continue
                 self.static_batch[k].copy_(v, non_blocking=True)
             else:
                 self.static_batch[k] = v
