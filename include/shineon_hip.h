@@ -25,6 +25,7 @@ extern "C" {
 
 #define SO_ERR_ALIGN (-1) /* pointer not 16-byte aligned / channel count or stride not a multiple of 4 */
 #define SO_ERR_SHAPE (-2) /* unsupported shape combination */
+#define SO_NOT_APPLICABLE (-3) /* a specialised entry point declines this problem: nothing was launched, use the general one */
 
 /* activation codes (models/networks/cpvton/unet.py:132-135,201-211; models/networks/activation.py) */
 #define SO_ACT_NONE_ 0
@@ -122,8 +123,8 @@ int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const fl
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
 /* csrc/pgemm.hip: the Winograd-domain batched products (C[b] = A[b] B[b]^T, K % 64 == 0, >= 16 matrices, >= 768 output tiles) run
- * on a PERSISTENT kernel that keeps its LDS-DMA pipeline running across output tiles; 1 = handled, 0 = not applicable (callers
- * fall back to so_gemm_batched).  so_pgemm_enable(0) switches it off (A/B measurements). */
+ * on a PERSISTENT kernel that keeps its LDS-DMA pipeline running across output tiles; 0 = launched, SO_NOT_APPLICABLE = declined,
+ * nothing launched (callers fall back to so_gemm_batched), anything else = an error (hipError_t / SO_ERR_*).  so_pgemm_enable(0) switches it off (A/B measurements). */
 int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, const float* B, int ldb, long long sb, float* C, int ldc,
                 long long sc, int batch, void* stream);
 void so_pgemm_enable(int on);
@@ -204,6 +205,10 @@ int so_act_fwd(const float* x, int ldx, float* y, int ldy, long long rows, int C
                float param, void* stream);
 int so_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx,
                long long rows, int C, int act, float param, void* stream);
+/* dx = res + dy * act'(x): gradient of a U-Net block input, which feeds the skip concatenation (gradient res) and the block's
+ * down activation (gradient dy of its output) - unet.py:187-198; replaces act_bwd + autograd's accumulation add, same bits. */
+int so_act_bwd_add(const float* x, int ldx, const float* dy, int lddy, const float* res, int ldres, float* dx, int lddx,
+                   long long rows, int C, int act, float param, void* stream);
 
 /* torch.cat(dim=1) / channel slicing / zero channel padding (unet.py:198; unet_mask_model.py:69):
  * dst[row][0:Cd] = src[row][0:Cs] (zero beyond Cs); accumulate != 0: dst += src. */

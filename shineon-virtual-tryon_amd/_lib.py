@@ -105,7 +105,8 @@ class HipKernelError(RuntimeError):
     pass
 
 
-_ERRS = {-1: "SO_ERR_ALIGN (pointer/stride/channel alignment)", -2: "SO_ERR_SHAPE (unsupported shape)"}
+_ERRS = {-1: "SO_ERR_ALIGN (pointer/stride/channel alignment)", -2: "SO_ERR_SHAPE (unsupported shape)",
+         -3: "SO_NOT_APPLICABLE (specialised entry point declined; nothing was launched)"}
 
 
 def check(err, what=""):

@@ -88,6 +88,12 @@ __device__ __forceinline__ float so_block_sum256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// A wave's LDS-DMA fills (`buffer_load ... lds`) are pending VM operations of THAT wave only: before a workgroup barrier
+// publishes an LDS stage to the other waves, every wave must have drained its own vmcnt.  hipcc happens to emit that
+// s_waitcnt in front of s_barrier; stating it keeps a compiler or flag change from turning every staged tile into a silent
+// cross-wave race (it merges with the compiler's own wait: no extra instruction in today's ISA).
+#define SO_DMA_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0); expcnt / lgkmcnt left at their maxima */
+
 static inline int so_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 #define SO_LAUNCH_CHECK() ((int)hipGetLastError())

@@ -86,6 +86,33 @@ __global__ __launch_bounds__(256) void act_bwd_k(const float* __restrict__ x, in
   }
 }
 
+// dx = res + dy * act'(x): the gradient of a tensor that feeds BOTH a skip connection (gradient `res`) and an activation
+// (gradient `dy` of the activation's output) - the U-Net block input, unet.py:187-198.  One rounding per operation, in the
+// order autograd's separate kernels use (multiply, then add; no fused multiply-add), so the bits equal act_bwd_k + a + b.
+template <int VEC>
+__global__ __launch_bounds__(256) void act_bwd_add_k(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ dy, int lddy,
+                                                     const float* __restrict__ res, int ldres,
+                                                     float* __restrict__ dx, int lddx, unsigned rows,
+                                                     unsigned C, int act, float param) {
+  const unsigned CQ = C / VEC;
+  const unsigned total = rows * CQ;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned row = idx / CQ, cq = idx - row * CQ;
+    const Pack<VEC> a = ldp<VEC>(x + (size_t)row * ldx + cq * VEC);
+    Pack<VEC> g = ldp<VEC>(dy + (size_t)row * lddy + cq * VEC);
+    const Pack<VEC> r = ldp<VEC>(res + (size_t)row * ldres + cq * VEC);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      // (hipcc contracts __fadd_rn(r, __fmul_rn(..)) into one v_fma_f32 like any a + b * c: switch contraction off lexically)
+#pragma clang fp contract(off)
+      const float prod = g.v[i] * so_actg(act, a.v[i], param);
+      g.v[i] = r.v[i] + prod;
+    }
+    stp<VEC>(dx + (size_t)row * lddx + cq * VEC, g);
+  }
+}
+
 // ------------------------------------------------------------------ strided 2-D copy / accumulate
 // dst[row][0:Cd] = (c < Cs ? src[row][c] : 0)   (zero channel padding when Cd > Cs); mode 1: dst += src
 template <int VEC>
@@ -793,6 +820,19 @@ int so_act_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, in
                        dx, lddx, (unsigned)rows, (unsigned)C, act, param);
   else
     hipLaunchKernelGGL(act_bwd_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, x, ldx, dy, lddy, dx,
+                       lddx, (unsigned)rows, (unsigned)C, act, param);
+  return SO_LAUNCH_CHECK();
+}
+
+int so_act_bwd_add(const float* x, int ldx, const float* dy, int lddy, const float* res, int ldres, float* dx, int lddx,
+                   long long rows, int C, int act, float param, void* stream) {
+  if (rows * C <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (VEC_OK2(x, ldx, dy, lddy, C) && (lddx & 3) == 0 && al16(dx) && (ldres & 3) == 0 && al16(res))
+    hipLaunchKernelGGL(act_bwd_add_k<4>, dim3(grid_for(rows * C / 4)), dim3(256), 0, st, x, ldx, dy, lddy, res, ldres,
+                       dx, lddx, (unsigned)rows, (unsigned)C, act, param);
+  else
+    hipLaunchKernelGGL(act_bwd_add_k<1>, dim3(grid_for(rows * C)), dim3(256), 0, st, x, ldx, dy, lddy, res, ldres, dx,
                        lddx, (unsigned)rows, (unsigned)C, act, param);
   return SO_LAUNCH_CHECK();
 }

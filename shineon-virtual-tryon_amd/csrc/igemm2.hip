@@ -649,11 +649,11 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
 #if SO_ABLATE & 8
 #define SO_SYNC()
 #else
-#define SO_SYNC() __syncthreads()
+#define SO_SYNC() do { SO_DMA_DRAIN(); __syncthreads(); } while (0)
 #endif
 
   // K loop.  Two LDS stages; the fill of tile t+1 is issued at the top of tile t into the stage all waves left at the barrier
-  // that ended tile t-1, and is drained by the vmcnt(0) hipcc puts in front of the barrier that ends tile t (an LDS-DMA is a
+  // that ended tile t-1, and is drained by SO_DMA_DRAIN (vmcnt(0), common.h) in front of the barrier that ends tile t (an LDS-DMA is a
   // pending LDS write on the VM counter): one whole tile - 16+ MFMAs per wave, times the blocks sharing the CU - to land.
   // sched_barrier(0) around that barrier keeps the MFMAs (which touch no memory) from sinking below it; the loop is unrolled
   // by two so that both stages are addressed statically, with no exit from the middle of the body (a second exit makes the
@@ -702,6 +702,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   read_frag(0, 0, fa[0], fb[0]);
   read_frag(0, 1, fa[1], fb[1]);
 #endif
+  SO_DMA_DRAIN();
   __syncthreads();
 
 #define SO_KTILE(CUR, kt_next)                                      \

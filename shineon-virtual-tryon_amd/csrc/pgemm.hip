@@ -140,18 +140,22 @@ __global__ __launch_bounds__(256, 3) void pgemm_nt_k(const PGemmP p) {
     if (has_next) setup(nxt, na_off, nb_off, nm0, nn0, nbz);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    __syncthreads();                  // K tile 0 of this item has landed (hipcc drains the LDS-DMA in front of the barrier)
+    SO_DMA_DRAIN();                   // K tile 0 of this item: every wave's own fills have landed (common.h) ...
+    __syncthreads();                  // ... before the barrier publishes the stage
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt + 2 < nk; kt += 2) {
       PG_TILE(0, fill(bz, a_off, b_off, kt + 1, 1));
+      SO_DMA_DRAIN();
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       PG_TILE(1, fill(bz, a_off, b_off, kt + 2, 0));
+      SO_DMA_DRAIN();
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
     }
     // the last two K tiles: the second one starts the NEXT item's pipeline
     PG_TILE(0, fill(bz, a_off, b_off, nk - 1, 1));
+    SO_DMA_DRAIN();
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     PG_TILE(1, if (has_next) fill(nbz, na_off, nb_off, 0, 0));
@@ -187,20 +191,20 @@ extern "C" {
 
 void so_pgemm_enable(int on) { g_pgemm = on; }
 
-// 1 = handled; 0 = not applicable (the caller uses the general engine); < 0 / hipError = failure
+// 0 = launched; SO_NOT_APPLICABLE = declined, nothing launched (the caller uses the general engine); anything else = failure
 int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, const float* B, int ldb, long long sb, float* C, int ldc,
                 long long sc, int batch, void* stream) {
-  if (!g_pgemm || batch < 16 || (K & 63) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || K < 128) return 0;
-  if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C)) & 15) return 0;
-  if ((sa & 3) || (sb & 3) || (sc & 3)) return 0;
+  if (!g_pgemm || batch < 16 || (K & 63) || (N & 3) || (lda & 3) || (ldb & 3) || (ldc & 3) || K < 128) return SO_NOT_APPLICABLE;
+  if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C)) & 15) return SO_NOT_APPLICABLE;
+  if ((sa & 3) || (sb & 3) || (sc & 3)) return SO_NOT_APPLICABLE;
   const long long ab = (long long)M * lda * 4, bb = (long long)N * ldb * 4;
-  if (ab <= 0 || bb <= 0 || ab >= 0x7FFFFFF0LL || bb >= 0x7FFFFFF0LL) return 0;
+  if (ab <= 0 || bb <= 0 || ab >= 0x7FFFFFF0LL || bb >= 0x7FFFFFF0LL) return SO_NOT_APPLICABLE;
   PGemmP p = {};
   p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.batch = batch;
   p.sa = sa; p.sb = sb; p.sc = sc; p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
   p.tiles_m = (M + 63) / 64; p.tiles_n = (N + 63) / 64;
   p.items = (long long)batch * p.tiles_m * p.tiles_n;
-  if (p.items < 768) return 0;     // fewer items than resident workgroups: nothing to pipeline across
+  if (p.items < 768) return SO_NOT_APPLICABLE;     // fewer items than resident workgroups: nothing to pipeline across
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pgemm_nt_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PG_LDS);
@@ -213,7 +217,7 @@ int so_pgemm_nt(int M, int N, int K, const float* A, int lda, long long sa, cons
   hipLaunchKernelGGL(pgemm_nt_k, dim3(grid), dim3(256), PG_LDS, (hipStream_t)stream, p);
   so_prof_end(slot, (hipStream_t)stream);
   const int err = SO_LAUNCH_CHECK();
-  return err ? err : 1;
+  return err;
 }
 
 }  // extern "C"

@@ -510,11 +510,13 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
       WF_MMA(3)
       __builtin_amdgcn_sched_barrier(0);
 #if !(WF_ABLATE & 8)
-      __syncthreads();   // (hipcc drains the LDS-DMA with vmcnt(0) in front of the barrier)
+      SO_DMA_DRAIN();    // every wave's own fills have landed before the barrier publishes the stage (common.h)
+      __syncthreads();
 #endif
       __builtin_amdgcn_sched_barrier(0);
     };
     dma_fill(0, 0);
+    SO_DMA_DRAIN();
     __syncthreads();
 #if WF_ABLATE & 16
     build_frags(0);
@@ -889,8 +891,7 @@ int so_wino_conv3x3(const float* x, int ldx, const float* U, const float* bias, 
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
   err = so_pgemm_nt((int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 16, stream);   // persistent short-K form
-  if (err == 1) err = 0;
-  else if (err == 0)
+  if (err == SO_NOT_APPLICABLE)   // declined (shape / alignment / switched off): the general engine
   err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 16, nullptr, nullptr, nullptr,
                         0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
   if (err) return err;
@@ -930,8 +931,7 @@ int so_wino4_conv3x3(const float* x, int ldx, const float* U, const float* bias,
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
   err = so_pgemm_nt((int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 36, stream);   // persistent short-K form
-  if (err == 1) err = 0;
-  else if (err == 0)
+  if (err == SO_NOT_APPLICABLE)   // declined (shape / alignment / switched off): the general engine
   err = so_gemm_batched(0, 1, (int)T, Ko, C, V, C, T * C, U, C, (long long)Ko * C, Mx, Ko, T * Ko, 36, nullptr, nullptr, nullptr,
                         0, 0, SO_ACT_NONE, 0.f, ws, ws_bytes, stream);
   if (err) return err;

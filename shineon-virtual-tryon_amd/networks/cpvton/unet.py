@@ -112,6 +112,11 @@ class UnetSkipConnectionBlock(nn.Module):
             mods = mods[1:]
         elif preact is not None:
             return SkipPair(x, _run(mods[1:], preact))
+        elif self.takes_preactivation() and x.is_cuda:
+            # x feeds the skip concatenation AND this block's down activation: one node for the pair, so that the backward pass
+            # merges the two gradients in the activation's own kernel (ops.fork_act) instead of an accumulation launch
+            xs, a = ops.fork_act(x, mods[0].kind, mods[0].param)
+            return SkipPair(xs, _run(mods[1:], a))
         return SkipPair(x, _run(mods, x))
 
     def takes_preactivation(self):
@@ -148,7 +153,8 @@ def _run(mods, h):
             i += 2
         elif (isinstance(m, HipInstanceNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], UnetSkipConnectionBlock)
               and mods[i + 1].takes_preactivation() and not isinstance(h, SkipPair) and h.is_cuda):
-            # norm -> [submodule: act -> conv ...]: the norm kernel writes act(y) beside y (y stays for the skip connection)
+            # norm -> [submodule: act -> conv ...]: the norm kernel writes act(y) beside y (y stays for the skip connection);
+            # (y, act(y)) come back as the two outputs of ONE autograd node (ops.fork_act)
             nxt = mods[i + 1]
             y, a = ops.instance_norm_act(h, m.eps, nxt.model[0].kind, nxt.model[0].param)
             h = nxt.forward_pair(y, preact=a)

@@ -723,6 +723,7 @@ class _NormFn(torch.autograd.Function):
         """act2 (an activation code): also return act2(y), written by the same launch - the consumer's first operation; that
         second output carries no gradient here (ops.instance_norm_act hangs the activation's own backward node on it)."""
         L = lib()
+        ctx.set_materialize_grads(False)   # no zero-filled gradient tensor (an ATen fill launch) for the second output
         x = to_rows(x)
         n, c, h, w = x.shape
         G, R = (n, h * w) if instance else (1, n * h * w)
@@ -753,6 +754,8 @@ class _NormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _da=None):
         L = lib()
+        if dy is None:
+            return (None,) * 11
         x, mean, rstd, gamma = ctx.saved_tensors
         G, R, relu_gate = ctx.cfg
         n, c, h, w = x.shape
@@ -784,27 +787,60 @@ def instance_norm(x, eps=1e-5):
     return _NormFn.apply(x, None, None, None, None, True, 0.0, eps)
 
 
-class _PrecomputedActFn(torch.autograd.Function):
-    """act(x) whose VALUE was already written by the kernel that produced x (so_norm_act_fwd): the forward launches nothing,
-    the backward is _ActFn's - so the autograd graph, its kernels and its bits are those of `activation(x)`."""
+class _ForkActFn(torch.autograd.Function):
+    """(x, act(x)) for a tensor that feeds BOTH a skip connection and an activation - every U-Net block input
+    (models/networks/cpvton/unet.py:187-198: `torch.cat([x, self.model(x)], 1)` with `self.model` starting with the block's
+    down activation).  Left to autograd that is act_bwd, then an accumulation add of the two gradients (an ATen launch);
+    here the backward pass is ONE kernel, dx = d_skip + d_act * act'(x), with the same roundings in the same order
+    (so_act_bwd_add), i.e. the same bits.  `a` given: the activation's VALUE was already written by the kernel that
+    produced x (so_norm_act_fwd) and the forward launches nothing."""
 
     @staticmethod
     def forward(ctx, x, a, act, param):
+        ctx.set_materialize_grads(False)
+        x = to_rows(x)
+        n, c, h, w = x.shape
+        if a is None:
+            a = nhwc_empty(n, h, w, c, x.device)
+            check(lib().so_act_fwd(x.data_ptr(), _ld(x), a.data_ptr(), c, n * h * w, c, act, param, _stream()), "act_fwd")
+        else:
+            a = a.detach()
         ctx.save_for_backward(x)
         ctx.cfg = (act, param)
-        return a.detach()
+        return x.view_as(x), a
 
     @staticmethod
-    def backward(ctx, dy):
-        return _ActFn.backward(ctx, dy) + (None,)
+    def backward(ctx, d_skip, d_act):
+        (x,) = ctx.saved_tensors
+        act, param = ctx.cfg
+        if d_act is None:
+            return d_skip, None, None, None
+        n, c, h, w = x.shape
+        d_act = to_rows(d_act)
+        dx = nhwc_empty(n, h, w, c, x.device)
+        if d_skip is None:
+            check(lib().so_act_bwd(x.data_ptr(), _ld(x), d_act.data_ptr(), _ld(d_act), dx.data_ptr(), c, n * h * w, c, act, param,
+                                   _stream()), "act_bwd")
+        else:
+            d_skip = to_rows(d_skip)
+            check(lib().so_act_bwd_add(x.data_ptr(), _ld(x), d_act.data_ptr(), _ld(d_act), d_skip.data_ptr(), _ld(d_skip),
+                                       dx.data_ptr(), c, n * h * w, c, act, param, _stream()), "act_bwd_add")
+        return dx, None, None, None
+
+
+def fork_act(x, kind, param=0.0, precomputed=None):
+    """(x_skip, act(x)): x_skip is x itself, routed through the node whose backward merges the skip gradient with the
+    activation's (see _ForkActFn)."""
+    code = ACT_CODES[kind] if not isinstance(kind, int) else kind
+    return _ForkActFn.apply(x, precomputed, code, float(param))
 
 
 def instance_norm_act(x, eps, kind, param=0.0):
     """(y, act(y)) with y = instance_norm(x): one launch for both - the U-Net hands y to the skip connection and act(y) to
-    the next block's convolution (models/networks/cpvton/unet.py:132-147, 187)."""
+    the next block's convolution (models/networks/cpvton/unet.py:132-147, 187); one backward kernel for the pair."""
     code = ACT_CODES[kind] if not isinstance(kind, int) else kind
     y, a = _NormFn.apply(x, None, None, None, None, True, 0.0, eps, False, code, float(param))
-    return y, _PrecomputedActFn.apply(y, a, code, float(param))
+    return _ForkActFn.apply(y, a, code, float(param))
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu_gate_input=False):
@@ -1405,6 +1441,7 @@ class _TryonComposeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, o, cloth):
         L = lib()
+        ctx.set_materialize_grads(False)   # p_rendered carries no loss term (unet_mask_model.py:165-188): no zero fill for it
         o, cloth = to_rows(o), to_rows(cloth)
         n, c, h, w = o.shape
         dev = o.device

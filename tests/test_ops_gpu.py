@@ -223,6 +223,33 @@ def test_instance_norm_with_the_consumers_activation_is_bit_identical(ops, cuda,
     assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(g1, g2)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16, 12), (1, 6, 5, 7)])   # 16-byte path / scalar path
+@pytest.mark.parametrize("kind", ["gelu", "leaky", "relu"])
+def test_fork_act_is_bit_identical_to_activation_plus_autograd_accumulation(ops, cuda, shape, kind):
+    """ops.fork_act: (x, act(x)) as ONE node (a U-Net block input feeds the skip concatenation and the down activation,
+    unet.py:187-198); its backward kernel dx = d_skip + d_act * act'(x) must give the bits of act_bwd followed by autograd's
+    accumulation add, and cope with either gradient missing."""
+    x = rnd(*shape, seed=81).to(cuda)
+    gs, ga = rnd(*shape, seed=82).to(cuda), rnd(*shape, seed=83).to(cuda)
+    x1 = x.clone().requires_grad_(True)
+    a1 = ops.activation(x1, kind, 0.2)
+    (g1,) = torch.autograd.grad((x1 * gs).sum() + (a1 * ga).sum(), x1)
+    x2 = x.clone().requires_grad_(True)
+    xs, a2 = ops.fork_act(x2, kind, 0.2)
+    (g2,) = torch.autograd.grad((xs * gs).sum() + (a2 * ga).sum(), x2)
+    assert torch.equal(xs, x) and torch.equal(a1, a2) and torch.equal(g1, g2)
+    # only the activation branch / only the skip branch carries a gradient
+    x3 = x.clone().requires_grad_(True)
+    _, a3 = ops.fork_act(x3, kind, 0.2)
+    (g3,) = torch.autograd.grad((a3 * ga).sum(), x3)
+    (g3_ref,) = torch.autograd.grad((ops.activation(x1, kind, 0.2) * ga).sum(), x1)
+    assert torch.equal(g3, g3_ref)
+    x4 = x.clone().requires_grad_(True)
+    xs4, _ = ops.fork_act(x4, kind, 0.2)
+    (g4,) = torch.autograd.grad((xs4 * gs).sum(), x4)
+    assert torch.equal(g4, gs)
+
+
 def test_instance_norm_known_answer(ops, cuda):
     y = ops.instance_norm(rnd(2, 8, 32, 24, seed=13).to(cuda) * 5 + 1)
     yc = ops.to_nchw(y).cpu()
@@ -532,7 +559,7 @@ def test_persistent_winograd_gemm_is_bit_identical_to_the_engine(cuda, M, N, K, 
     for rep in range(2):
         out = torch.full((batch, M, N), float("nan"), device=cuda)
         rc = L.so_pgemm_nt(M, N, K, A.data_ptr(), K, M * K, B.data_ptr(), K, N * K, out.data_ptr(), N, M * N, batch, st)
-        assert rc == 1, rc
+        assert rc == 0, rc   # 0 = launched (SO_NOT_APPLICABLE = -3 would mean it declined)
         torch.cuda.synchronize()
         assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
     # and against fp64 on a slice

@@ -42,7 +42,7 @@ def main():
                                         None, None, 0, 0, 0, 0.0, ws.data_ptr(), ws.numel() * 4, st)
         per = lambda: L.so_pgemm_nt(M, N, K, A.data_ptr(), K, M * K, B.data_ptr(), K, N * K, C.data_ptr(), N, M * N, nb, st)  # noqa: E731
         te = timed(eng)
-        applicable = per() == 1
+        applicable = per() == 0   # 0 = launched, SO_NOT_APPLICABLE (-3) = declined
         tp = timed(per) if applicable else float("nan")
         gf = 2.0 * M * N * K * nb / 1e9
         print(f"{M}x{N}x{K} b{nb}: engine {te:6.1f} us {gf / te * 1e3:6.1f} TF   persistent {tp:6.1f} us {gf / tp * 1e3 if applicable else 0:6.1f} TF", flush=True)
