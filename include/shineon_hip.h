@@ -122,6 +122,19 @@ int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const fl
 /* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
+/* csrc/attn.hip: SAGAN self-attention core for n = H*W <= 256 positions (sagan.py:38-52) on qkv = [q | k | v] rows ([B n][E], the
+ * output of ONE projection GEMM).  so_attn_supported: 1 when the fused kernels take the shape (C % 32 == 0, d % 4 == 0, LDS fits);
+ * so_attn_fwd: energy -> softmax -> attention x V -> gamma * o + x in one launch (a: [B][n][n], o: [B n][C], both may be NULL);
+ * so_attn_bwd: dqkv = [dq | dk | dv] from dout in two launches (ws: so_attn_ws_floats floats, 8-byte aligned);
+ * so_attn_tail: db[0:E] (+)= column sums of dqkv and dgamma (+)= <dout, o> (fp64 partials left in ws by so_attn_bwd). */
+int so_attn_supported(int B, int n, int C, int d);
+long long so_attn_ws_floats(int B, int n);
+int so_attn_fwd(const float* qkv, int E, int d, const float* x, int ldx, const float* gamma, float* a, float* o, float* out,
+                int ldout, int B, int n, int C, void* stream);
+int so_attn_bwd(const float* qkv, int E, int d, const float* a, const float* o, const float* dout, int lddout,
+                const float* gamma, float* dqkv, float* ws, int B, int n, int C, void* stream);
+int so_attn_tail(const float* dqkv, int E, const float* ws, int B, int n, float* db, int acc_db, float* dgamma, int acc_gamma,
+                 void* stream);
 /* csrc/pgemm.hip: the Winograd-domain batched products (C[b] = A[b] B[b]^T, K % 64 == 0, >= 16 matrices, >= 768 output tiles) run
  * on a PERSISTENT kernel that keeps its LDS-DMA pipeline running across output tiles; 0 = launched, SO_NOT_APPLICABLE = declined,
  * nothing launched (callers fall back to so_gemm_batched), anything else = an error (hipError_t / SO_ERR_*).  so_pgemm_enable(0) switches it off (A/B measurements). */

@@ -10,6 +10,8 @@ synchronisation inside `training_step`; gradients must already be views of the o
 """
 import torch
 
+from . import ops
+
 # Thread-local capture: with a process group alive, ProcessGroupNCCL's watchdog thread polls the events of recent collectives
 # (hipEventQuery) - under the default GLOBAL capture mode such a call from ANOTHER thread is "not permitted when stream is
 # capturing", invalidates the capture and kills the process (seen in about one start in six over a one-rank RCCL group; it
@@ -55,7 +57,7 @@ class GraphedTrainStep:
         if self.exchange is not None:
             self.exchange.begin()
         res = self.model.training_step(self.static_batch, 0)
-        res.minimize.backward()
+        ops.backward(res.minimize)
         if self.exchange is not None:
             self.exchange.end()
         # keep only detached values: a live autograd graph would pin the parameters' AccumulateGrad nodes to the
@@ -105,8 +107,6 @@ class GraphedChainedStep:
         """exchange_w / exchange_u: trainer.BucketedExchange of the warp / try-on optimizer - their counter bump and "bucket
         ready" signal kernels become nodes of the warp-backward / try-on graph, so each model's gradient buckets can be
         exchanged and applied while the rest of its backward pass is still running."""
-        from . import ops
-
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
         if hasattr(warp, "tower_streams"):
             warp.tower_streams = False   # the warp stage already runs beside the try-on stage: no third stream (warp_model.py)
@@ -128,7 +128,7 @@ class GraphedChainedStep:
                 rw = warp.training_step(sb, 0)
                 if exw is not None:
                     exw.begin()
-                rw.minimize.backward()
+                ops.backward(rw.minimize)
                 if exw is not None:
                     exw.end()
             b2 = dict(self.batch_tryon)
@@ -137,7 +137,7 @@ class GraphedChainedStep:
             if exu is not None:
                 exu.begin()
             ru = unet.training_step(b2, 0)
-            ru.minimize.backward()
+            ops.backward(ru.minimize)
             if exu is not None:
                 exu.end()
 
@@ -158,7 +158,7 @@ class GraphedChainedStep:
             with torch.cuda.graph(self.g_wb, stream=cs, capture_error_mode=capture_mode()):
                 if exw is not None:
                     exw.begin()
-                rw.minimize.backward()
+                ops.backward(rw.minimize)
                 if exw is not None:
                     exw.end()
         self.result_warp = _detached(rw)
@@ -173,7 +173,7 @@ class GraphedChainedStep:
             if exu is not None:
                 exu.begin()
             ru = unet.training_step(b2, 0)
-            ru.minimize.backward()
+            ops.backward(ru.minimize)
             if exu is not None:
                 exu.end()
         self.result_tryon = _detached(ru)
@@ -231,27 +231,10 @@ class GraphedChainedStep:
 
 
 def _side_stream():
-    """The stream of the warp stage.  SHINEON_SIDE_CUS=<n> (experiment): confine it to the first n compute units with
-    hipExtStreamCreateWithCUMask, so that the warp stage's many short kernels would fill in beside the try-on stage's large
-    GEMMs without taking CUs from all of them.  Measured on MI355X (bench.py c4): 8.98 ms/step unmasked, 19.1 / 14.5 / 11.9 /
-    11.2 ms with 32 / 64 / 128 / 192 CUs - the warp forward sits on the next step's critical path, so slowing it stalls the
-    pipeline; left in as a switch, off by default."""
-    import ctypes
-    import os
-
-    n = int(os.environ.get("SHINEON_SIDE_CUS", "0") or 0)
-    if n <= 0:
-        return torch.cuda.Stream()
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (n + 31) // 32
-    mask = (ctypes.c_uint32 * 8)(*([0] * 8))
-    for i in range(n):
-        mask[i // 32] |= 1 << (i % 32)
-    stream = ctypes.c_void_p()
-    err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(max(words, 8)), mask)
-    if err != 0:
-        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {err}")
-    return torch.cuda.ExternalStream(stream.value)
+    """The stream of the warp stage.  (Confining it to a subset of the compute units - hipExtStreamCreateWithCUMask - was
+    measured in round 1: 19.1 / 14.5 / 11.9 / 11.2 ms per step with 32 / 64 / 128 / 192 CUs against 8.98 unmasked, because the
+    warp forward sits on the next step's critical path; the switch was removed in round 6.)"""
+    return torch.cuda.Stream()
 
 
 def _detached(res):

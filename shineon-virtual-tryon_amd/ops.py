@@ -89,10 +89,8 @@ def workspace(device, min_bytes=0, lane=0):
 
 
 _SIDE = {}
-# Input gradients of trainable convolutions read the OHWI weights in place (the engine transposes while staging);
-# SHINEON_DGRAD_IN_PLACE=0 goes back to a transposed copy per step (measured 0.05 ms/step slower).  The frozen VGG
-# chain always uses cached transposed weights.
-DGRAD_IN_PLACE = os.environ.get("SHINEON_DGRAD_IN_PLACE", "1") != "0"
+# Input gradients of trainable convolutions read the OHWI weights in place (the engine stages them untransposed; a transposed
+# copy per step measured 0.05 ms/step slower and was removed).  The frozen VGG chain uses cached transposed weights.
 # Split-bf16 convolutions for the FROZEN VGG19 chain (csrc/sb16.hip): fp32 = hi + mid bf16 planes, three bf16 MFMAs per
 # product instead of one fp32 MFMA stream at 1/16 of the rate.  Not bit-equal to the fp32 path (error ~3x the fp32 MFMA
 # chain's own round-off), so it is OFF by default and reported as its own bench line (bench.py --vgg-split-bf16).
@@ -455,20 +453,13 @@ class _Conv2dFn(torch.autograd.Function):
                 u = _wino_weights(w, None, True, fused=wino == "fused", ko_pad=op, f44=wino == "nonfused4")
                 wino_conv3x3(dy.data_ptr(), _ld(dy), u, None, None, dxp.data_ptr(), cp, n, h, wd, op, cp, ACT_NONE, dev,
                              fused=wino == "fused", f44=wino == "nonfused4")
-            elif DGRAD_IN_PLACE:
+            else:
                 # trainable weights change every step: read them in place (OHWI rows are contiguous along the GEMM
-                # column c; the engine transposes while staging) instead of writing a transposed copy per step
+                # column c) instead of writing a transposed copy per step
                 check(
                     L.so_conv2d_dgrad(dy.data_ptr(), _ld(dy), _pad_rows(w, op).data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op,
                                       r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
                     "conv2d_dgrad",
-                )
-            else:
-                wt = _ihwo(_pad_rows(w, op))  # transposed weights: both GEMM operands k-contiguous (same mode as fprop)
-                check(
-                    L.so_conv2d_dgrad_t(dy.data_ptr(), _ld(dy), wt.data_ptr(), dxp.data_ptr(), cp, n, h, wd, cp, op, r, s,
-                                        stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-                    "conv2d_dgrad_t",
                 )
             dx = dxp if cp == i else dxp[:, :i]
         if need_w or need_b:
@@ -955,6 +946,66 @@ class _SelfAttentionQkvFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None
 
 
+class _SelfAttentionCoreFn(torch.autograd.Function):
+    """_SelfAttentionQkvFn's layout (one projection GEMM into [rows][2d + C]; input, weight and bias gradients of the three
+    projections as one GEMM / one column sum each, accumulated straight into the gradient slab) with everything between the
+    projections in csrc/attn.hip: energy -> softmax -> attention x V -> gamma * o + x is ONE launch, its backward pass three
+    (so_attn_bwd's two + so_attn_tail, which also finishes d gamma) - 8 launches per module forward + backward instead of the
+    composed form's 15 + split-K reduces, each of which costs >= 5 us as a graph node."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, gamma):
+        L = lib()
+        x = _dense_rows(x)
+        b, c, h, w = x.shape
+        n, d = h * w, wq.shape[0]
+        E = 2 * d + c
+        dev = x.device
+        ldx, xp = _ld(x), x.data_ptr()
+        qkv = torch.empty((b * n, E), dtype=torch.float32, device=dev)
+        _gemm(0, 1, b * n, E, c, xp, ldx, 0, wq.data_ptr(), c, 0, qkv.data_ptr(), E, 0, 1, bias=bq.data_ptr(), device=dev)
+        a = torch.empty((b, n, n), dtype=torch.float32, device=dev)
+        o = torch.empty((b * n, c), dtype=torch.float32, device=dev)
+        out = nhwc_empty(b, h, w, c, dev)
+        check(L.so_attn_fwd(qkv.data_ptr(), E, d, xp, ldx, gamma.data_ptr(), a.data_ptr(), o.data_ptr(), out.data_ptr(), c,
+                            b, n, c, _stream()), "attn_fwd")
+        ctx.save_for_backward(x, qkv, a, o, gamma)
+        ctx.params = (wq, bq, gamma)  # first tensors of the adjacent weight / bias runs, and gamma
+        ctx.ready = (wq, bq, wk, bk, wv, bv, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = lib()
+        x, qkv, a, o, gamma = ctx.saved_tensors
+        wq, bq, gpar = ctx.params
+        b, c, h, w = x.shape
+        n = h * w
+        E = qkv.shape[1]
+        d = (E - c) // 2
+        dev = x.device
+        dout = _dense_rows(dout)
+        ldg, gp = _ld(dout), dout.data_ptr()
+        dqkv = torch.empty((b * n, E), dtype=torch.float32, device=dev)
+        scratch = torch.empty(L.so_attn_ws_floats(b, n), dtype=torch.float32, device=dev)   # dE + the fp64 d gamma partials
+        check(L.so_attn_bwd(qkv.data_ptr(), E, d, a.data_ptr(), o.data_ptr(), gp, ldg, gamma.data_ptr(), dqkv.data_ptr(),
+                            scratch.data_ptr(), b, n, c, _stream()), "attn_bwd")
+        # dx = dout + [dq | dk | dv] [Wq; Wk; Wv]
+        dx = nhwc_empty(b, h, w, c, dev)
+        _gemm(0, 0, b * n, c, E, dqkv.data_ptr(), E, 0, wq.data_ptr(), c, 0, dx.data_ptr(), c, 0, 1, res=gp, ldres=ldg, device=dev)
+        # [dWq; dWk; dWv] += [dq | dk | dv]^T x, in place in the gradient slab
+        wg = wq.grad.data_ptr()
+        _gemm(1, 0, E, c, b * n, dqkv.data_ptr(), E, 0, x.data_ptr(), _ld(x), 0, wg, c, 0, 1, res=wg, ldres=c, device=dev)
+        # [dbq; dbk; dbv] += column sums of dqkv;  d gamma += <dout, o>
+        check(L.so_attn_tail(dqkv.data_ptr(), E, scratch.data_ptr(), b, n, bq.grad.data_ptr(), 1, gpar.grad.data_ptr(), 1,
+                             _stream()), "attn_tail")
+        grad_ready(*ctx.ready)
+        return dx, None, None, None, None, None, None, None
+
+
+# tools / tests: False sends every shape through the composed engine launches (A/B of csrc/attn.hip against them)
+ATTN_CORE = True
+
 _QKV_CACHE = {}
 
 
@@ -1100,8 +1151,12 @@ def _self_attention_forward_only(x, wcat, bcat, gamma, d):
     qkv = f(b * n, E)
     _gemm(0, 1, b * n, E, c, xp, ldx, 0, wcat.data_ptr(), c, 0, qkv.data_ptr(), E, 0, 1, bias=bcat.data_ptr(), device=dev)
     qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + d * 4, qkv.data_ptr() + 2 * d * 4
-    e, a = f(b * n, n), f(b * n, n)
     out = nhwc_empty(b, h, w, c, dev)
+    if ATTN_CORE and L.so_attn_supported(b, n, c, d):   # one launch for everything behind the projection (csrc/attn.hip)
+        check(L.so_attn_fwd(qkv.data_ptr(), E, d, xp, ldx, gamma.data_ptr(), None, None, out.data_ptr(), c, b, n, c, _stream()),
+              "attn_fwd")
+        return out
+    e, a = f(b * n, n), f(b * n, n)
     _gemm(0, 1, n, n, d, qp, E, n * E, kp, E, n * E, e.data_ptr(), n, n * n, b, device=dev)
     check(L.so_softmax_rows_fwd(e.data_ptr(), n, a.data_ptr(), n, b * n, n, _stream()), "softmax_fwd")
     # gamma * (attention x V) + x in the product's epilogue (alpha, residual): o itself is only needed by d gamma
@@ -1116,11 +1171,16 @@ def self_attention(x, wq, bq, wk, bk, wv, bv, gamma):
         if stacked is not None:
             return _self_attention_forward_only(x, stacked[0], stacked[1], gamma, wq.shape[0])
     ws_, bs_ = (wq, wk, wv), (bq, bk, bv)
-    fused = (x.is_cuda and wq.shape[0] % 4 == 0 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0
-             and all(_direct_grad_ok(t, ohwi=True) for t in ws_) and all(_direct_grad_ok(t, ohwi=False) for t in bs_)
-             and _direct_grad_ok(gamma, ohwi=False) and _adjacent(ws_) and _adjacent(bs_)
-             and _adjacent([t.grad for t in ws_]) and _adjacent([t.grad for t in bs_]))
-    fn = _SelfAttentionQkvFn if fused else _SelfAttentionFn
+    # q/k/v weights, biases and their gradients adjacent in the optimizer's slab: one GEMM serves the three projections
+    slab = (x.is_cuda and wq.shape[0] % 4 == 0 and x.shape[1] % 4 == 0
+            and all(_direct_grad_ok(t, ohwi=True) for t in ws_) and all(_direct_grad_ok(t, ohwi=False) for t in bs_)
+            and _direct_grad_ok(gamma, ohwi=False) and _adjacent(ws_) and _adjacent(bs_)
+            and _adjacent([t.grad for t in ws_]) and _adjacent([t.grad for t in bs_]))
+    n = x.shape[2] * x.shape[3]
+    if slab and ATTN_CORE and lib().so_attn_supported(x.shape[0], n, x.shape[1], wq.shape[0]):
+        fn = _SelfAttentionCoreFn      # n <= 256 positions (any n, also ragged): the fused core of csrc/attn.hip
+    else:
+        fn = _SelfAttentionQkvFn if slab and n % 4 == 0 else _SelfAttentionFn
     return fn.apply(x, wq, bq, wk, bk, wv, bv, gamma)
 
 
@@ -1423,6 +1483,26 @@ def zero_scalar(device):
     if z is None:
         z = _ZERO[key] = torch.zeros((), dtype=torch.float32, device=device)
     return z
+
+
+_ONE = {}
+
+
+def one_scalar(device):
+    """A constant 0-dim one: the root gradient of `loss.backward(...)` (autograd otherwise launches a fill for it every step)."""
+    key = (device.type, device.index)
+    o = _ONE.get(key)
+    if o is None:
+        o = _ONE[key] = torch.ones((), dtype=torch.float32, device=device)
+    return o
+
+
+def backward(loss):
+    """loss.backward() with the cached unit root gradient (one ATen fill launch less per backward pass)."""
+    if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32:
+        loss.backward(one_scalar(loss.device))
+    else:
+        loss.backward()
 
 
 def scalar_sum(*terms):

@@ -23,6 +23,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .options import str2num
 
 logger = logging.getLogger("logger")
@@ -86,7 +87,7 @@ class GradientAllReducer:
     def __init__(self, flat_grads, n_buckets=4, group=None):
         self.flat = flat_grads
         self.group = group
-        n_buckets = max(1, int(os.environ.get("SHINEON_REDUCER_BUCKETS", n_buckets)))
+        n_buckets = max(1, int(n_buckets))
         n = flat_grads.numel()
         step = (n + n_buckets - 1) // n_buckets
         step = (step + 1023) // 1024 * 1024
@@ -160,7 +161,7 @@ class BucketedExchange:
         table = optimizer.slot_table()
         total = optimizer.flat_grads.numel()
         want = max(1, int(bucket_bytes) // 4)
-        n_min = int(os.environ.get("SHINEON_BUCKETS_MIN", "2"))     # at least two, so that something can overlap
+        n_min = 2     # at least two buckets, so that something can overlap
         n_b = max(n_min, min(len(table), (total + want - 1) // want))
         per = (total + n_b - 1) // n_b
         self.buckets = []   # [lo, hi, parameters] in slab order
@@ -194,9 +195,8 @@ class BucketedExchange:
             raise RuntimeError("hipHostMalloc of the abort / status words failed")
         self._words = (ctypes.c_uint32 * 2).from_address(self.words)
         self.deadline_ticks = int(float(os.environ.get("SHINEON_WAIT_DEADLINE_S", "60")) * 1e8)   # 100 MHz wall clock
-        # 1 = one-lane polling kernel (default), 0 = hipStreamWaitValue32: the command-processor wait slows the dispatch of
-        # every kernel of the step it waits through (6.64 vs 5.87 ms/step measured on c3), the polling kernel does not
-        self.wait_mode = int(os.environ.get("SHINEON_WAIT_MODE", "1"))
+        # the waiter is a one-lane polling kernel (so_stream_wait_ge_bounded).  hipStreamWaitValue32 was measured and removed:
+        # the command-processor wait slows the dispatch of every kernel of the step it waits through (6.64 vs 5.87 ms/step, c3)
 
     def __del__(self):
         try:
@@ -271,7 +271,7 @@ class BucketedExchange:
                 ev = torch.cuda.Event()
                 ev.record(st)
                 cur.wait_event(ev)
-        self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), int(self.wait_mode == 0), self._stream()),
+        self._check(self.L.so_signal_store(self.flags[b], self.counter.data_ptr(), 0, self._stream()),
                     "signal_store")
         self._signalled.add(b)
 
@@ -323,11 +323,8 @@ class BucketedExchange:
         flat = self.opt.flat_grads
         for b in self.order:
             lo, hi, _ = self.buckets[b]
-            if self.wait_mode == 0:
-                self._check(self.L.so_stream_wait_ge(self.flags[b], self.step_no, 0, self.comm.cuda_stream), "stream_wait_ge")
-            else:
-                self._check(self.L.so_stream_wait_ge_bounded(self.flags[b], self.step_no, self.words, self.deadline_ticks,
-                                                             self.comm.cuda_stream), "stream_wait_ge_bounded")
+            self._check(self.L.so_stream_wait_ge_bounded(self.flags[b], self.step_no, self.words, self.deadline_ticks,
+                                                         self.comm.cuda_stream), "stream_wait_ge_bounded")
             with torch.cuda.stream(self.comm):
                 if self.active:
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
@@ -509,7 +506,7 @@ class TrainStep:
         if self.exchange is not None:
             self.exchange.begin()
         res = self.model.training_step(batch, 0)
-        (res.minimize / self.accumulate if self.accumulate > 1 else res.minimize).backward()
+        ops.backward(res.minimize / self.accumulate if self.accumulate > 1 else res.minimize)
         if self.exchange is not None:
             self.exchange.end()
         self._micro += 1
@@ -588,8 +585,8 @@ class ChainedTrainStep:
                                             bucketed 8.39 ms - the warp model's buffer broadcast of step k+1 queues behind
                                             the try-on all-reduce of step k on RCCL's stream, i.e. behind the END of the
                                             try-on graph, and the two-stream overlap is lost
-          try-on exchange on its own        whole-slab 6.87 ms (+0.22), bucketed 6.73 ms (+0.07)   <- what is built
-          communicator (`group_u`)
+          try-on exchange on its own        whole-slab 6.87 ms (+0.22), bucketed 6.73 ms (+0.07) - removed in round 6
+          communicator                      (deadlock-prone with real peers; the default below needs no second one)
         Also tried: collectives issued on the graph streams themselves (8.31 ms); GPU_MAX_HW_QUEUES=8 (doubles the step time
         with or without collectives)."""
         self.warp, self.optw, self.unet, self.optu = warp, optw, unet, optu
@@ -606,17 +603,15 @@ class ChainedTrainStep:
         # What made one communicator slow in round 3 (+0.62 ms/step) was the warp model's per-step buffer broadcast queueing
         # behind the try-on all-reduce, i.e. behind the end of the try-on graph; the broadcast is now LAZY (see
         # `lazy_buffers`), which removes that collective from the step altogether.
-        # SHINEON_TWO_COMMUNICATORS=1: the try-on exchange on its own communicator / stream with the per-bucket exchange
-        # (round 3's schedule; measured 6.73 vs 6.87 ms over the one-rank group) - opt-in until it has met a real wire.
-        two = os.environ.get("SHINEON_TWO_COMMUNICATORS", "0") == "1"
-        self.group_u = dist.new_group() if (_collective() and two) else None
-        self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads, group=self.group_u)
+        # (Round 3's second communicator for the try-on exchange - 0.1 ms less exposed over the one-rank group - was removed in
+        # round 6: it never met a real wire and is the deadlock-prone arrangement.)
+        self.redw, self.redu = GradientAllReducer(optw.flat_grads), GradientAllReducer(optu.flat_grads)
         self.exw = self.exu = None
-        if bucketed is None and os.environ.get("SHINEON_BUCKETED") is None and not two:
+        if bucketed is None and os.environ.get("SHINEON_BUCKETED") is None:
             bucketed = False   # whole-slab exchange after each graph: host-ordered on the one communicator
         if schedule != "eager":
             self.exw = _make_exchange(optw, bucketed, bucket_bytes)
-            self.exu = _make_exchange(optu, bucketed, bucket_bytes, group=self.group_u) if self.exw is not None else None
+            self.exu = _make_exchange(optu, bucketed, bucket_bytes) if self.exw is not None else None
         self.sync_buffers = sync_buffers and _collective() and flatten_float_buffers(warp) is not None
         # BatchNorm running statistics are not READ by a training-mode forward, so DDP's per-forward broadcast of rank 0's
         # buffers only matters when somebody looks at them: validation, a checkpoint, the end of training.  Lazy = rank 0's
@@ -747,14 +742,14 @@ class ChainedTrainStep:
             broadcast_buffers(self.warp)
         self.optw.zero_grad()
         rw = self.warp.training_step(batch, 0)
-        rw.minimize.backward()
+        ops.backward(rw.minimize)
         if update:
             self.optw.step(grad_scale=self.redw.all_reduce())
         b2 = dict(batch)
         b2["cloth"] = self.warp.warped_cloth.detach()
         self.optu.zero_grad()
         ru = self.unet.training_step(b2, 0)
-        ru.minimize.backward()
+        ops.backward(ru.minimize)
         if update:
             self.optu.step(grad_scale=self.redu.all_reduce())
         return rw, ru

@@ -92,18 +92,16 @@ for key, (o0, _) in plain.items():
         if a is o1._flat[1]:
             continue   # the gradient slab: scratch
         assert torch.equal(a, b), (key, float((a - b).abs().max()))
-for bucketed, two in ((False, "0"), (True, "0"), (False, "1"), (True, "1")):
-    os.environ["SHINEON_TWO_COMMUNICATORS"] = two   # "1": the try-on exchange on its own communicator (round 3's schedule)
+for bucketed in (False, True):
     opts, eng = run_chained(bucketed)
-    assert (eng.exu is not None) == bucketed and eng.redu.active and (eng.group_u is not None) == (two == "1")
+    assert (eng.exu is not None) == bucketed and eng.redu.active
     for o1, o0 in zip(opts, chained_plain):
         assert o1._steps == o0._steps == 3
         for a, b in zip(o1._flat, o0._flat):
             if a is o1._flat[1]:
                 continue
             assert torch.equal(a, b), ("chained", bucketed, float((a - b).abs().max()))
-    print("chained", "bucketed" if bucketed else "whole-slab", "two communicators" if two == "1" else "one communicator",
-          "bit-identical", flush=True)
+    print("chained", "bucketed" if bucketed else "whole-slab", "one communicator", "bit-identical", flush=True)
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK", flush=True)

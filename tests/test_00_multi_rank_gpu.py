@@ -125,8 +125,8 @@ def _run_one(cmd, env):
         pytest.fail(f"{' '.join(cmd[-6:])} did not finish within {CHILD_TIMEOUT_S} s (killed):\n{out[-1500:]}\n{err[-2500:]}")
 
 
-@pytest.mark.parametrize("extra,bucketed,two", [([], None, None), (["--config", "c3"], None, None), ([], "1", "1"), ([], "1", "0")])
-def test_bench_over_a_single_rank_rccl_group(extra, bucketed, two):
+@pytest.mark.parametrize("extra,bucketed", [([], None), (["--config", "c3"], None), ([], "1")])
+def test_bench_over_a_single_rank_rccl_group(extra, bucketed):
     """bench.py with the one-rank RCCL group: the N > 1 code path (broadcasts, exchange, MAX-over-ranks timing, the
     with / without-collectives measurement behind config.exchange_exposed_ms) over the nccl backend on one GPU."""
     import json
@@ -135,8 +135,6 @@ def test_bench_over_a_single_rank_rccl_group(extra, bucketed, two):
     env = dict(os.environ, SHINEON_SINGLE_RANK_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if bucketed is not None:
         env["SHINEON_BUCKETED"] = bucketed   # c4: per-bucket exchange released inside each model's backward (default: whole slab)
-    if two is not None:
-        env["SHINEON_TWO_COMMUNICATORS"] = two   # c4: the try-on exchange on its own communicator (round 3's schedule; opt-in)
     env["SHINEON_DIST_TIMEOUT_S"] = "120"
     p = _run_one(cmd, env)
     assert p.returncode == 0, p.stderr[-4000:]

@@ -264,10 +264,12 @@ def test_attention_head_dim_not_multiple_of_4(cuda):
     assert_close(sa.key_conv.bias.grad, pc["a.key_conv.bias"].grad, atol=1e-4, what="attention d=5 dbk")
 
 
-@pytest.mark.parametrize("c,hw", [(64, (4, 3)), (128, (8, 6))])
+@pytest.mark.parametrize("c,hw", [(64, (4, 3)), (128, (8, 6)), (512, (16, 12)), (96, (5, 7)), (64, (20, 16))])
 def test_self_attention_fused_qkv_path(cuda, c, hw):
     """With HipAdam's slab layout (q/k/v weights, biases and gradients adjacent) the three projections and their
-    gradients run as single GEMMs accumulating into the gradient slab; same numbers as the oracle."""
+    gradients run as single GEMMs accumulating into the gradient slab; same numbers as the oracle.  Up to 256 positions
+    everything between the projections is the fused core of csrc/attn.hip (the U-Net's 4x3 / 8x6 / 16x12 maps at 512
+    channels, a ragged 5x7 map), beyond that (20x16) the composed engine launches."""
     from oracle.procedural import procedural_state_dict
     from shineon_virtual_tryon_amd import ops
     from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
@@ -285,7 +287,9 @@ def test_self_attention_fused_qkv_path(cuda, c, hw):
     x = torch.randn(2, c, hw[0], hw[1], generator=torch.Generator().manual_seed(12))
     xg = x.clone().to(cuda).requires_grad_(True)
     y = sa(xg)
-    assert type(y.grad_fn).__name__.startswith("_SelfAttentionQkvFn")
+    core = bool(ops.lib().so_attn_supported(2, hw[0] * hw[1], c, c // 8))
+    assert core == (hw[0] * hw[1] <= 256)
+    assert type(y.grad_fn).__name__.startswith("_SelfAttentionCoreFn" if core else "_SelfAttentionQkvFn")
     xc = x.clone().requires_grad_(True)
     pc = {"a." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
     yr = oracle.self_attention(xc, pc, "a")
@@ -295,7 +299,9 @@ def test_self_attention_fused_qkv_path(cuda, c, hw):
     (yr * seed).sum().backward()
     assert_close(xg.grad, xc.grad, atol=1e-4, what="fused attention dx")
     for name, prm in sa.named_parameters():
-        assert_close(prm.grad, pc["a." + name].grad, atol=1e-4, rtol=1e-4, what=f"fused attention d{name}")
+        ref_g = pc["a." + name].grad
+        # (at 512 channels x 192 positions the weight gradients reach ~50: fp32 round-off scales with the tensor's magnitude)
+        assert_close(prm.grad, ref_g, atol=1e-4 * max(1.0, float(ref_g.abs().max())), rtol=1e-4, what=f"fused attention d{name}")
 
 
 @pytest.mark.parametrize("which", ["warp", "unet_mask"])
