@@ -211,6 +211,13 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
                 long long R, int C, const float* mean, const float* rstd, const float* gamma,
                 float* dgamma, float* dbeta, int accumulate, int relu_gate, float* ws, void* stream);
 
+/* so_norm_bwd that also leaves dbias[c] (+)= sum over the rows of dx[r][c] (G == 1): the bias gradient of the convolution in
+ * front of a Conv -> ReLU -> BatchNorm group (warp.py:15-31), taken from the backward statistics pass (two launches less). */
+int so_norm_bwd_bias(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                     long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                     float* dgamma, float* dbeta, int accumulate, int relu_gate, float* dbias, int accumulate_bias,
+                     float* ws, void* stream);
+
 /* ---- pointwise / resampling / reductions (csrc/elementwise.hip) ---------------------------------- */
 
 /* LeakyReLU / ReLU / GELU / Swish / Sine / tanh / sigmoid (unet.py:132-135,201-211) */

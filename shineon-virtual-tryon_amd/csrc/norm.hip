@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
   }
 }
 
-// Backward partial sums per (g, chunk, c): s1 = sum dy, s2 = sum dy * xhat.   part: [G][nchunk][2][C]
+// Backward partial sums per (g, chunk, c): s1 = sum dy, s2 = sum dy * xhat.   part: [G][nchunk][NS][C], NS = 2, or 5 with
+// GATED = true: also the sums over the rows with x > 0 of dy, 1 and xhat - from them norm_bwd_final_k gets the column sums of
+// the GATED input gradient (the bias gradient of the Conv -> ReLU in front of this BatchNorm, warp.py:15-31) without another
+// pass over dx:  sum_r dx = rstd gamma (sum_{x>0} dy - s1/R #{x>0} - s2/R sum_{x>0} xhat).
+template <bool GATED>
 __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ dy, int lddy,
                                                           unsigned R, unsigned C, unsigned chunk,
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restric
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
                                                           float* __restrict__ part) {
-  __shared__ float r1s[256], r2s[256];
+  constexpr int NS = GATED ? 5 : 2;
+  __shared__ float red[NS][256];
   const unsigned CPB = C >= 256 ? 256 : C;
   const unsigned RL = 256 / CPB;
   const unsigned tx = threadIdx.x % CPB, ty = threadIdx.x / CPB;
@@ -179,7 +184,9 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restric
   const unsigned r0 = blockIdx.x * chunk;
   unsigned r1 = r0 + chunk;
   if (r1 > R) r1 = R;
-  float s1 = 0.f, s2 = 0.f;
+  float s[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) s[k] = 0.f;
   if (ty < RL && col < C) {
     const float mu = mean[(size_t)g * C + col], rs = rstd[(size_t)g * C + col];
     const float* bx = x + (size_t)g * R * ldx;
@@ -187,49 +194,79 @@ __global__ __launch_bounds__(256) void norm_bwd_partial_k(const float* __restric
 #pragma unroll 8
     for (unsigned r = r0 + ty; r < r1; r += RL) {
       const float d = bd[(size_t)r * lddy + col];
-      const float xh = (bx[(size_t)r * ldx + col] - mu) * rs;
-      s1 += d;
-      s2 += d * xh;
+      const float xv = bx[(size_t)r * ldx + col];
+      const float xh = (xv - mu) * rs;
+      s[0] += d;
+      s[1] += d * xh;
+      if constexpr (GATED) {
+        const bool on = xv > 0.f;
+        s[2] += on ? d : 0.f;
+        s[3] += on ? 1.f : 0.f;
+        s[4] += on ? xh : 0.f;
+      }
     }
   }
-  r1s[threadIdx.x] = s1; r2s[threadIdx.x] = s2;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) red[k][threadIdx.x] = s[k];
   __syncthreads();
   if (ty == 0 && col < C) {
-    float a = 0.f, b = 0.f;
-    for (unsigned l = 0; l < RL; ++l) { a += r1s[l * CPB + tx]; b += r2s[l * CPB + tx]; }
-    float* o = part + ((size_t)g * nchunk + blockIdx.x) * 2 * C;
-    o[col] = a; o[C + col] = b;
+    float* o = part + ((size_t)g * nchunk + blockIdx.x) * NS * C;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      float a = 0.f;
+      for (unsigned l = 0; l < RL; ++l) a += red[k][l * CPB + tx];
+      o[k * C + col] = a;
+    }
   }
 }
 
-// sums[g][2][C]; optional dgamma/dbeta (BatchNorm: G == 1) with accumulate flag.
+// sums[g][2][C]; optional dgamma/dbeta (BatchNorm: G == 1) with accumulate flag; GATED: dbias (see norm_bwd_partial_k).
+template <bool GATED>
 __global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict__ part,
                                                         unsigned nchunk, unsigned C,
                                                         float* __restrict__ sums,
                                                         float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int accumulate) {
-  __shared__ float sa[1024], sb[1024];
+                                                        float* __restrict__ dbeta, int accumulate,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        float invR, float* __restrict__ dbias, int accumulate_bias) {
+  constexpr int NS = GATED ? 5 : 2;
+  __shared__ float sa[NS][1024];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
-  float a = 0.f, b = 0.f;
+  float a[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) a[k] = 0.f;
   if (c < C) {
 #pragma unroll 4
     for (unsigned k = ty; k < nchunk; k += 64) {
-      const float* o = part + ((size_t)g * nchunk + k) * 2 * C;
-      a += o[c]; b += o[C + c];
+      const float* o = part + ((size_t)g * nchunk + k) * NS * C;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) a[q] += o[q * C + c];
     }
   }
-  sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) sa[q][threadIdx.x] = a[q];
   __syncthreads();
   if (ty != 0 || c >= C) return;
-  a = 0.f; b = 0.f;
-  for (unsigned l = 0; l < 64; ++l) { a += sa[l * 16 + tx]; b += sb[l * 16 + tx]; }
-  sums[(size_t)g * 2 * C + c] = a;
-  sums[(size_t)g * 2 * C + C + c] = b;
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    float t = 0.f;
+    for (unsigned l = 0; l < 64; ++l) t += sa[q][l * 16 + tx];
+    a[q] = t;
+  }
+  sums[(size_t)g * 2 * C + c] = a[0];
+  sums[(size_t)g * 2 * C + C + c] = a[1];
   if (dgamma) {
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + b;
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + a;
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + a[1];
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + a[0];
+  }
+  if constexpr (GATED) {
+    if (dbias) {   // G == 1
+      const float sc = gamma ? rstd[c] * gamma[c] : rstd[c];
+      const float v = sc * (a[2] - a[0] * invR * a[3] - a[1] * invR * a[4]);
+      dbias[c] = (accumulate_bias ? dbias[c] : 0.f) + v;
+    }
   }
 }
 
@@ -352,7 +389,8 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
                                                          int lddx, unsigned R, unsigned C,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                         float* __restrict__ dbeta, int accumulate, int relu_gate) {
+                                                         float* __restrict__ dbeta, int accumulate, int relu_gate,
+                                                         float* __restrict__ dbias, int accumulate_bias) {
   __shared__ float p1[32][33], p2[32][33];
   __shared__ float b1[32], b2[32];
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -383,17 +421,30 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
     }
   }
   __syncthreads();
-  if (!live) return;
+  if (!live && !dbias) return;
   const float invR = 1.0f / (float)R;
   const float a = b1[tx] * invR, b = b2[tx] * invR;
-  const float sc = gamma ? rs * gamma[col] : rs;
+  const float sc = (live && gamma) ? rs * gamma[col] : rs;
   float* bo = dx + (size_t)g * R * lddx + col;
+  float sb = 0.f;
 #pragma unroll 8
-  for (unsigned r = ty; r < R; r += 32) {
+  for (unsigned r = ty; live && r < R; r += 32) {
     const float xv = bx[(size_t)r * ldx];
     const float xh = (xv - mu) * rs;
-    const float v = (bd[(size_t)r * lddy] - a - xh * b) * sc;
-    bo[(size_t)r * lddx] = (relu_gate && !(xv > 0.f)) ? 0.f : v;
+    float v = (bd[(size_t)r * lddy] - a - xh * b) * sc;
+    if (relu_gate && !(xv > 0.f)) v = 0.f;
+    bo[(size_t)r * lddx] = v;
+    sb += v;
+  }
+  if (!dbias) return;    // kernel argument: uniform
+  // column sums of the input gradient just written = the bias gradient of the convolution in front (G == 1)
+  __syncthreads();
+  p1[ty][tx] = sb;
+  __syncthreads();
+  if (ty == 0 && live) {
+    float t = 0.f;
+    for (unsigned l = 0; l < 32; ++l) t += p1[l][tx];
+    dbias[col] = (accumulate_bias ? dbias[col] : 0.f) + t;
   }
 }
 
@@ -426,7 +477,7 @@ extern "C" {
 long long so_norm_ws_floats(int G, long long R, int C) {
   unsigned chunk, nchunk;
   chunking(R, C, chunk, nchunk);
-  return (long long)G * nchunk * 3 * C + (long long)G * 2 * C;
+  return (long long)G * nchunk * 5 * C + (long long)G * 2 * C;   // backward partials: up to 5 sums per (chunk, column)
 }
 
 // Training-mode statistics + normalisation.  mean/rstd: [G][C] outputs (saved for backward).
@@ -491,28 +542,41 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
   return SO_LAUNCH_CHECK();
 }
 
-int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
-                long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                float* dgamma, float* dbeta, int accumulate, int relu_gate, float* ws, void* stream) {
+static int norm_bwd_launch(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                           long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                           float* dgamma, float* dbeta, int accumulate, int relu_gate, float* dbias, int accumulate_bias,
+                           float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
-  if (dgamma && G != 1) return SO_ERR_SHAPE;
+  if ((dgamma || dbias) && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (R <= kSmallRows) {
     hipLaunchKernelGGL(norm_small_bwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, dy, lddy, dx, lddx,
-                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate);
+                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, dbias, accumulate_bias);
     return SO_LAUNCH_CHECK();
   }
   unsigned chunk, nchunk;
   chunking(R, C, chunk, nchunk);
   const unsigned CPB = C >= 256 ? 256 : (unsigned)C;
   float* part = ws;
-  float* sums = ws + (size_t)G * nchunk * 3 * C;
+  float* sums = ws + (size_t)G * nchunk * 5 * C;
   dim3 g1(nchunk, so_cdiv(C, CPB), G);
-  hipLaunchKernelGGL(norm_bwd_partial_k, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
-                     (unsigned)C, chunk, nchunk, mean, rstd, part);
   dim3 g2(so_cdiv(C, 16), G);
-  hipLaunchKernelGGL(norm_bwd_final_k, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
-                     dbeta, accumulate);
+  const float invR = 1.0f / (float)R;
+  if (dbias && relu_gate) {
+    hipLaunchKernelGGL(norm_bwd_partial_k<true>, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
+                       (unsigned)C, chunk, nchunk, mean, rstd, part);
+    hipLaunchKernelGGL(norm_bwd_final_k<true>, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
+                       dbeta, accumulate, rstd, gamma, invR, dbias, accumulate_bias);
+  } else {
+    hipLaunchKernelGGL(norm_bwd_partial_k<false>, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
+                       (unsigned)C, chunk, nchunk, mean, rstd, part);
+    hipLaunchKernelGGL(norm_bwd_final_k<false>, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
+                       dbeta, accumulate, rstd, gamma, invR, (float*)nullptr, 0);
+    if (dbias) {
+      // ungated: the column sums of dx are -rstd gamma s2/R sum_r xhat = 0 up to round-off (sum_r xhat = 0): exact zero
+      if (!accumulate_bias) (void)hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
+    }
+  }
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && al16(x) && al16(dy) && al16(dx) && al16(mean) &&
       al16(rstd) && al16(sums))
@@ -522,6 +586,25 @@ int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, i
     hipLaunchKernelGGL(norm_bwd_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, dy, lddy,
                        dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   return SO_LAUNCH_CHECK();
+}
+
+int so_norm_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                float* dgamma, float* dbeta, int accumulate, int relu_gate, float* ws, void* stream) {
+  return norm_bwd_launch(x, ldx, dy, lddy, dx, lddx, G, R, C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, nullptr, 0,
+                         ws, stream);
+}
+
+// so_norm_bwd that also leaves dbias[c] (+)= sum over the rows of dx[r][c] (G must be 1): the bias gradient of the
+// convolution whose (ReLU-gated) output this BatchNorm normalises (Conv -> ReLU -> BatchNorm, models/networks/cpvton/warp.py:
+// 15-31) - from the backward statistics pass itself instead of a column-sum pass over dx (two launches less per layer).
+int so_norm_bwd_bias(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
+                     long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                     float* dgamma, float* dbeta, int accumulate, int relu_gate, float* dbias, int accumulate_bias,
+                     float* ws, void* stream) {
+  if (!dbias) return SO_ERR_SHAPE;
+  return norm_bwd_launch(x, ldx, dy, lddy, dx, lddx, G, R, C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, dbias,
+                         accumulate_bias, ws, stream);
 }
 
 }  // extern "C"

@@ -960,7 +960,8 @@ int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int f
 // Output channels per block: 32 (three blocks per CU) or 64 for Ko >= 64 (two blocks per CU; the A fragments of a lane's
 // tile - 8 LDS reads + 32 VALU - feed 32 MFMAs instead of 16).  With LDS-DMA staging the 64-channel form wins wherever its grid
 // still covers the chip twice over (VGG conv1_2 / conv2_x on 8 images: 163 vs 169 us, 146 vs 155 us; equal on 4 images; it
-// loses on the small layers, 51 vs 48 us at 144 blocks - profiles/r05_wino_dma_ab.txt): chosen per launch from the grid size.
+// loses on the small layers, 51 vs 48 us at 144 blocks - profiles/r05_wino_dma_ab.txt) and, since round 6, has >= 128 input
+// channels: chosen per launch.
 // so_wino_fused_force_kb32: 1 = always 32, 0 = 64 whenever Ko >= 64, -1 (default) = that rule.
 static int g_wino_force_nkg1 = -1;
 void so_wino_fused_force_kb32(int on) { g_wino_force_nkg1 = on; }
@@ -1007,7 +1008,10 @@ static int wino_fused_launch(const float* x, int ldx, const float* U, const floa
   int nkg = 1;   // output channels per block: 32, or 64 (two groups per wave)
   if (Ko >= 64 && g_wino_force_nkg1 <= 0) {
     const long long blocks64 = (long long)Nb * p.pbx * p.pby * ((Ko + 63) / 64);
-    if (g_wino_force_nkg1 == 0 || (g_wino_dma && blocks64 >= 1024)) nkg = 2;
+    // (round 6, warm clocks, 8 images: 64 -> 64 at 256x192 136.5 vs 133.1 us, 64 -> 128 at 128x96 69.8 vs 68.4: with only
+    //  8 K steps per block the third resident block of the 32-channel form covers more of the per-block prologue / epilogue
+    //  than the shared A fragments save; 128 -> 128 at 128x96 120.5 vs 123.7 the other way - profiles/r06_wino_stagger_experiment.txt)
+    if (g_wino_force_nkg1 == 0 || (g_wino_dma && blocks64 >= 1024 && C >= 128)) nkg = 2;
   }
   const int KB = 32 * nkg;
   p.nkb = (Ko + KB - 1) / KB; p.nks = (C + 7) / 8;

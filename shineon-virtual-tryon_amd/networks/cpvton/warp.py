@@ -46,9 +46,13 @@ class FeatureExtraction(nn.Module):
             if isinstance(m, HipConv2d) and not m.fuse_relu and i + 1 < len(mods) and isinstance(mods[i + 1], HipReLU):
                 bn = mods[i + 2] if i + 2 < len(mods) and isinstance(mods[i + 2], HipBatchNorm2d) else None
                 gate = bn is not None and bn.training and torch.is_grad_enabled()
-                x = ops.conv2d(x, m.weight, m.bias, m.stride, m.padding, ops.ACT_RELU, act_grad_external=gate)
+                # the convolution's bias gradient = column sums of the gradient the BatchNorm hands back: with the bias in the
+                # optimizer's slab the BatchNorm's own backward statistics pass accumulates it (no column-sum launches)
+                ext = gate and m.bias is not None and m.bias.requires_grad and ops._direct_grad_ok(m.bias, False)
+                x = ops.conv2d(x, m.weight, m.bias, m.stride, m.padding, ops.ACT_RELU, act_grad_external=gate,
+                               bias_grad_external=ext)
                 if bn is not None:
-                    x = bn(x, relu_gate_input=gate)
+                    x = bn(x, relu_gate_input=gate, conv_bias=m.bias if ext else None)
                 i += 3 if bn is not None else 2
             else:
                 x = m(x)

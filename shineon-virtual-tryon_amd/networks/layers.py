@@ -91,14 +91,15 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._shared_counter = False  # True: the owner model bumps all counters with one launch (share_bn_counters)
 
-    def forward(self, x, relu_gate_input=False):
+    def forward(self, x, relu_gate_input=False, conv_bias=None):
         """relu_gate_input (training only): x is a ReLU output whose producer leaves the ReLU's backward mask to this
-        layer (see ops.batch_norm_train)."""
+        layer (see ops.batch_norm_train); conv_bias: that producer's bias parameter - its gradient (the column sums of the
+        gated input gradient) then comes out of this layer's backward statistics pass."""
         if self.training:
             if self.count_batches and not self._shared_counter:
                 self.num_batches_tracked += 1
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                        self.momentum, self.eps, relu_gate_input=relu_gate_input)
+                                        self.momentum, self.eps, relu_gate_input=relu_gate_input, conv_bias=conv_bias)
         return ops.batch_norm_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps)
 
 

@@ -314,9 +314,10 @@ class _Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0,
-                bias_grad_hint=False, forward_only=False):
+                bias_grad_hint=False, forward_only=False, bias_grad_external=False):
         L = lib()
         ctx.bias_hint = bool(bias_grad_hint)
+        ctx.bias_external = bool(bias_grad_external)
         if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
             # the backward pass evaluates act' from the OUTPUT, which only sign-preserving piecewise-linear maps allow
             raise ValueError("conv2d fuses ReLU / LeakyReLU only")
@@ -387,6 +388,8 @@ class _Conv2dFn(torch.autograd.Function):
         w_direct, b_direct = ctx.direct
         need_w = ctx.needs_input_grad[1]
         need_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.bias_external:
+            need_b = False   # the BatchNorm behind this convolution's ReLU accumulates it (batch_norm_train(conv_bias=...))
         plain = cp == i and op == o  # no channel padding anywhere: kernels can write the slab layout directly
         keep = []  # temporaries of the side stream must outlive the join
 
@@ -465,17 +468,21 @@ class _Conv2dFn(torch.autograd.Function):
         if need_w or need_b:
             dw, db = weight_grads(lane=0)
         grad_ready(w_direct, b_direct)   # both the input- and the weight-gradient kernels of this layer are in the stream
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False,
-           act_param=0.0, bias_grad_hint=False):
+           act_param=0.0, bias_grad_hint=False, bias_grad_external=False):
     """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
     output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
     act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
-    (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel."""
+    (batch_norm_train(relu_gate_input=True)), so the backward pass skips its own mask kernel.
+    bias_grad_external: that consumer also accumulates THIS convolution's bias gradient into the optimizer's slab
+    (batch_norm_train(conv_bias=bias)); the backward pass here then computes none."""
+    if bias_grad_external and not (bias is not None and _direct_grad_ok(bias, False)):
+        raise RuntimeError("conv2d(bias_grad_external=True) needs a bias whose gradient lives in the optimizer's slab")
     return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param, bias_grad_hint,
-                           _forward_only(x, weight, bias))
+                           _forward_only(x, weight, bias), bias_grad_external)
 
 
 def _forward_only(*ts):
@@ -710,7 +717,7 @@ class _NormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, instance, momentum, eps, relu_gate_input=False, act2=None,
-                act2_param=0.0):
+                act2_param=0.0, conv_bias=None):
         """act2 (an activation code): also return act2(y), written by the same launch - the consumer's first operation; that
         second output carries no gradient here (ops.instance_norm_act hangs the activation's own backward node on it)."""
         L = lib()
@@ -735,6 +742,13 @@ class _NormFn(torch.autograd.Function):
                                     *tail), "norm_act_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma)
         ctx.cfg = (G, R, bool(relu_gate_input))
+        # Conv -> ReLU -> BatchNorm: the bias gradient of that convolution = the column sums of the gated gradient this node
+        # returns; with the bias living in the optimizer's slab the backward pass accumulates it there (so_norm_bwd_bias)
+        if conv_bias is not None and not (relu_gate_input and not instance and _direct_grad_ok(conv_bias, False)
+                                          and conv_bias.numel() == c):
+            raise RuntimeError("batch_norm_train(conv_bias=...) needs relu_gate_input, batch statistics and a bias whose "
+                               "gradient lives in the optimizer's slab (the producing convolution skips its own bias gradient)")
+        ctx.conv_bias = conv_bias
         # affine parameters living in the optimizer's flat slab get their gradients accumulated in place
         ctx.direct = (gamma, beta) if gamma is not None and _direct_grad_ok(gamma, False) and _direct_grad_ok(beta, False) else None
         if a is None:
@@ -746,7 +760,7 @@ class _NormFn(torch.autograd.Function):
     def backward(ctx, dy, _da=None):
         L = lib()
         if dy is None:
-            return (None,) * 11
+            return (None,) * 12
         x, mean, rstd, gamma = ctx.saved_tensors
         G, R, relu_gate = ctx.cfg
         n, c, h, w = x.shape
@@ -761,17 +775,15 @@ class _NormFn(torch.autograd.Function):
             dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
             gptr, bptr = dgamma.data_ptr(), dbeta.data_ptr()
         ws = workspace(x.device, L.so_norm_ws_floats(G, R, c) * 4)
-        check(
-            L.so_norm_bwd(
-                x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
-                gamma.data_ptr() if gamma is not None else None,
-                gptr, bptr, int(ctx.direct is not None), int(relu_gate), ws.data_ptr(), _stream(),
-            ),
-            "norm_bwd",
-        )
+        head = (x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), dx.data_ptr(), c, G, R, c, mean.data_ptr(), rstd.data_ptr(),
+                gamma.data_ptr() if gamma is not None else None, gptr, bptr, int(ctx.direct is not None), int(relu_gate))
+        if ctx.conv_bias is not None:
+            check(L.so_norm_bwd_bias(*head, ctx.conv_bias.grad.data_ptr(), 1, ws.data_ptr(), _stream()), "norm_bwd_bias")
+        else:
+            check(L.so_norm_bwd(*head, ws.data_ptr(), _stream()), "norm_bwd")
         if ctx.direct is not None:
             grad_ready(*ctx.direct)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def instance_norm(x, eps=1e-5):
@@ -834,10 +846,12 @@ def instance_norm_act(x, eps, kind, param=0.0):
     return _ForkActFn.apply(y, a, code, float(param))
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu_gate_input=False):
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu_gate_input=False, conv_bias=None):
     """relu_gate_input: x is the output of a ReLU whose producer skips its own backward mask (conv2d(...,
-    act_grad_external=True)); the returned input gradient is then the one in front of that ReLU."""
-    return _NormFn.apply(x, gamma, beta, running_mean, running_var, False, momentum, eps, relu_gate_input)
+    act_grad_external=True)); the returned input gradient is then the one in front of that ReLU.  conv_bias: the bias
+    parameter of that producing convolution - its gradient is accumulated by this node's backward pass (so_norm_bwd_bias)
+    when it lives in the optimizer's slab, and the convolution's own backward then skips its column sums."""
+    return _NormFn.apply(x, gamma, beta, running_mean, running_var, False, momentum, eps, relu_gate_input, None, 0.0, conv_bias)
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):

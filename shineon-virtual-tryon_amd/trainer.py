@@ -153,6 +153,10 @@ class BucketedExchange:
         from ._lib import check, lib
 
         self.opt, self.group = optimizer, group
+        # False (round 6): ONE Adam pass behind the last bucket's all-reduce.  True = the update of each bucket right behind its
+        # all-reduce, i.e. beside the rest of the backward pass: measured over the one-rank RCCL group on c3 the HBM-bound update
+        # slows the backward kernels by what it saves (786.8 / 788.2 vs 793.7 / 789.5 frames/s, profiles/r06_single_rank_rccl.txt)
+        self.adam_per_bucket = False
         self.L, self._check = lib(), check
         if not self.L.so_signal_can_wait():
             raise RuntimeError("this device does not support hipStreamWaitValue32; use GradientAllReducer")
@@ -328,7 +332,13 @@ class BucketedExchange:
             with torch.cuda.stream(self.comm):
                 if self.active:
                     dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
-                self.opt.step_range(lo, hi, grad_scale=scale)
+                if self.adam_per_bucket:
+                    self.opt.step_range(lo, hi, grad_scale=scale)
+        if not self.adam_per_bucket:
+            # ONE Adam pass over the whole slab behind the last bucket's all-reduce: element-wise, so bit-identical to the
+            # per-bucket form - which ran its HBM-bound update beside the backward pass and slowed that by what it saved
+            with torch.cuda.stream(self.comm):
+                self.opt.step_range(0, flat.numel(), grad_scale=scale)
         self._launched = True
 
     def finish(self):

@@ -258,9 +258,68 @@ def case_c3_bench_inputs():
     return out
 
 
+def case_c2_bench_inputs():
+    """Forward only, on the inputs bench.py TIMES for the warp stage (c2 / c4): synthetic_batch(4, seed=420, smooth=False).
+    theta (full), the TPS grid (as (B, 2, H, W), 1/2 lattice + whole-tensor checksums) and the loss of the REFERENCE's own
+    WarpModel in training mode (models/warp_model.py:63-98); fp64 from the oracle.  The warped cloth is not recorded: on
+    white-noise cloth every bilinear tap flip is an O(1) difference (VERDICT r05 item 8 asks for theta and the grid)."""
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+
+    assert USE_REFERENCE, "this case records the reference's own forward: run it in the build container"
+    batch = synthetic_batch(4, "cpu", seed=420, smooth=False)
+    _, sd = fc.build_warp()
+    out = {"digest:weights": gf.input_digest(sd), "digest:batch": gf.input_digest(batch), "fp32_source": np.array("reference")}
+    _, r32, _ = reference_warp(sd, batch)
+    _, r64 = oracle_warp(sd, batch, torch.float64)
+    b = r32["theta"].shape[0]
+    gf.pack_output(out, "theta", r32["theta"].reshape(b, 1, 1, -1), r64["theta"].reshape(b, 1, 1, -1), stride=1)
+    gf.pack_output(out, "grid", r32["grid"].permute(0, 3, 1, 2), r64["grid"].permute(0, 3, 1, 2), stride=2)
+    out["log32:loss/G"] = np.float64(float(r32["loss/G"]))
+    out["log64:loss/G"] = np.float64(float(r64["loss/G"]))
+    return out
+
+
 # ---- SAMS --------------------------------------------------------------------------------------------
+def reference_sams_three_steps(sd, hp, batch):
+    """models/sams_model.py:147-383 on the reference's own SamsModel, in Lightning 0.9's multi-optimizer order (only the
+    current optimizer's parameters require grad): the structure sams_helpers.oracle_three_steps returns - per step (logs,
+    gradients by state_dict key), the generated frames of step 0, the state_dict after the three steps."""
+    mg = _reference()
+    from models.sams_model import SamsModel
+
+    ns = mg.hp_namespace(**vars(hp))
+    torch.manual_seed(0)
+    model = SamsModel(ns)
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+    model.train()
+    nets = {0: ("generator", model.generator), 1: ("multiscale_discriminator", model.multiscale_discriminator),
+            2: ("temporal_discriminator", model.temporal_discriminator)}
+    out, frames = [], None
+    for idx in (0, 1, 2):
+        own, net = nets[idx]
+        for q in model.parameters():
+            q.requires_grad = False
+        for q in net.parameters():
+            q.requires_grad = True
+        model.zero_grad()
+        res = model.training_step(dict(batch), 0, idx)
+        res.minimize.sum().backward()
+        if idx == 0:
+            frames = model.all_gen_frames.detach().clone()
+        out.append(({k: float(v.detach().sum()) for k, v in res.logs.items()},
+                    {f"{own}.{k}": q.grad.detach().clone() for k, q in net.named_parameters() if q.grad is not None}))
+    return out, frames, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
 def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True, o97=False):
-    ref32, frames32, sd32 = sh.oracle_three_steps(sd, hp, batch)
+    if USE_REFERENCE:   # round 6: the fp32 leg is the reference's own SamsModel (VERDICT r05 item 8 ii)
+        ref32, frames32, sd32 = reference_sams_three_steps(sd, hp, batch)
+        oref, _, _ = sh.oracle_three_steps(sd, hp, batch) if o97 else (None, None, None)
+        out["fp32_source"] = np.array("reference")
+    else:
+        ref32, frames32, sd32 = sh.oracle_three_steps(sd, hp, batch)
+        oref = ref32
+        out["fp32_source"] = np.array("oracle")
     ref64, frames64, sd64 = sh.oracle_three_steps(sd, hp, batch, torch.float64)
     kinks = sh.kink_spread(sd, hp, batch, ref64) if fp64_kinks else [None] * 3
     out["digest:weights"] = gf.input_digest(sd)
@@ -270,8 +329,8 @@ def _sams_three_steps(sd, hp, batch, out, fp64_kinks=True, o97=False):
             out[f"log32:{idx}:{k}"] = np.float64(ref32[idx][0][k])
             out[f"log64:{idx}:{k}"] = np.float64(ref64[idx][0][k])
         gf.pack_grads(out, f"grad{idx}:", ref32[idx][1], ref64[idx][1], kinks[idx])
-        if o97:  # the fp32 oracle at the sample positions of the REFERENCE goldens (tests/golden/sams_*.npz, gs<idx>: keys)
-            for k, v in ref32[idx][1].items():
+        if o97:  # the fp32 ORACLE at the sample positions of the REFERENCE goldens (tests/golden/sams_*.npz, gs<idx>: keys)
+            for k, v in oref[idx][1].items():
                 out[f"o97:{idx}:{k}"] = v.detach().contiguous().reshape(-1)[::97].float().numpy()
     f32 = frames32.reshape(frames32.shape[0], -1, *frames32.shape[-2:])
     f64 = frames64.reshape(frames64.shape[0], -1, *frames64.shape[-2:])
@@ -360,15 +419,29 @@ def case_sams_full_generator_bs4():
         o.backward(gout.to(dtype))
         return o.detach(), {k[len("generator."):]: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}
 
-    o32, g32 = run(torch.float32)
+    def run_reference():
+        """models/networks/sams/sams_generator.py:240-291 on the reference's own SamsGenerator (training mode)."""
+        mg = _reference()
+        from models.networks.sams.sams_generator import SamsGenerator
+
+        torch.manual_seed(0)
+        gen = SamsGenerator(mg.hp_namespace(**vars(hp)))
+        gen.load_state_dict({k[len("generator."):]: v.clone() for k, v in sd.items()}, strict=True)
+        gen.train()
+        o = gen(prev_frames.clone(), prev_maps.clone(), {k: v.clone() for k, v in maps.items()})
+        o.backward(gout)
+        return o.detach(), {k: q.grad.detach().clone() for k, q in gen.named_parameters() if q.grad is not None}
+
+    o32o, g32o = run(torch.float32)
+    o32, g32 = run_reference() if USE_REFERENCE else (o32o, g32o)
     o64, g64 = run(torch.float64)
     spread = {}
-    for sign in (1.0, -1.0):  # as the r03 test: the bracket from two more FP32 passes at this size
+    for sign in (1.0, -1.0):  # as the r03 test: the bracket from two more FP32 passes at this size (oracle against oracle)
         with sh.kink_shift(sign * sh.KINK_DELTA):
             _, g = run(torch.float32)
         for k, v in g.items():
-            spread[k] = max(spread.get(k, 0.0), (v - g32[k]).abs().max().item())
-    out = {"digest:weights": gf.input_digest(sd),
+            spread[k] = max(spread.get(k, 0.0), (v - g32o[k]).abs().max().item())
+    out = {"digest:weights": gf.input_digest(sd), "fp32_source": np.array("reference" if USE_REFERENCE else "oracle"),
            "digest:inputs": gf.input_digest({"pf": prev_frames, "pm": prev_maps, "gout": gout, **maps})}
     gf.pack_output(out, "out", o32, o64)
     out["out:max64"] = np.float64(o64.abs().max().item())
@@ -378,7 +451,7 @@ def case_sams_full_generator_bs4():
 
 CASES = {
     "warp_bs2": case_warp_bs2, "chain_bs4": case_chain_bs4, "chain_bs8": case_chain_bs8,
-    "c5": case_c5, "c5_bs2": case_c5_bs2, "c3_bench_inputs": case_c3_bench_inputs, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
+    "c5": case_c5, "c5_bs2": case_c5_bs2, "c3_bench_inputs": case_c3_bench_inputs, "c2_bench_inputs": case_c2_bench_inputs, "sams_base": case_sams_base, "sams_attn_gelu": case_sams_attn_gelu,
     "sams_progressive": case_sams_progressive, "sams_full_generator_bs4": case_sams_full_generator_bs4,
     "sams_full_three_steps": case_sams_full_three_steps,
 }

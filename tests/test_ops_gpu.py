@@ -292,6 +292,40 @@ def test_conv_relu_batchnorm_fused_gate(ops, cuda, hw):
                     [(x, True), (w, True), (b, True), (g, True), (be, True)], cuda, atol=2e-5, gatol=1e-4, what=f"conv+relu+bn {hw}")
 
 
+@pytest.mark.parametrize("hw", [(8, 6), (40, 28)])  # single-launch norm (R <= 1024 rows) / three-kernel norm
+def test_conv_bias_gradient_from_the_batchnorm_backward(ops, cuda, hw):
+    """Conv -> ReLU -> BatchNorm with the parameters in the optimizer's slab (FeatureExtraction.forward, warp.py:15-31): the
+    convolution's bias gradient - the column sums of the gated gradient the BatchNorm returns - comes out of the BatchNorm's
+    backward statistics pass (so_norm_bwd_bias: summed in the one-launch kernel, analytically from five column sums in the
+    three-kernel path) and the convolution computes none.  Against torch, and against the path that sums the columns of dx."""
+    from shineon_virtual_tryon_amd.optim import HipAdam
+
+    x = rnd(2, 8, hw[0], hw[1], seed=50)
+    seed_out = rnd(2, 16, hw[0], hw[1], seed=55)
+    vals = dict(w=rnd(16, 8, 3, 3, seed=51, scale=0.15), b=rnd(16, seed=52, scale=0.1), g=rnd(16, seed=53) * 0.1 + 1,
+                be=rnd(16, seed=54) * 0.1)
+    got = {}
+    for ext in (True, False):
+        prm = {k: torch.nn.Parameter(v.clone().to(cuda)) for k, v in vals.items()}
+        opt = HipAdam(list(prm.values()), lr=1e-3)
+        opt.zero_grad()
+        assert ops._direct_grad_ok(prm["b"], False)
+        rm, rv = torch.zeros(16, device=cuda), torch.ones(16, device=cuda)
+        y = ops.conv2d(x.to(cuda), prm["w"], prm["b"], 1, 1, ops.ACT_RELU, act_grad_external=True, bias_grad_external=ext)
+        out = ops.batch_norm_train(y, prm["g"], prm["be"], rm, rv, 0.1, 1e-5, relu_gate_input=True,
+                                   conv_bias=prm["b"] if ext else None)
+        (out * seed_out.to(cuda)).sum().backward()
+        got[ext] = {k: v.grad.detach().clone().cpu() for k, v in prm.items()}
+    ref = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    o = F.batch_norm(F.relu(F.conv2d(x, ref["w"], ref["b"], padding=1)), torch.zeros(16), torch.ones(16), ref["g"], ref["be"],
+                     True, 0.1, 1e-5)
+    (o * seed_out).sum().backward()
+    for k in vals:
+        assert_close(got[True][k], ref[k].grad, atol=1e-4,
+                     what=f"d{k} with the bias gradient from the BatchNorm backward {hw}")
+        assert_close(got[True][k], got[False][k], atol=1e-4 if k == "b" else 0.0, what=f"d{k}: BatchNorm-side vs column sums {hw}")
+
+
 @pytest.mark.parametrize("kind,ref", [("relu", F.relu), ("gelu", F.gelu), ("leaky", lambda t: F.leaky_relu(t, 0.2))])
 @pytest.mark.parametrize("c", [8, 6])
 def test_activation_fused_into_upsample(ops, cuda, kind, ref, c):

@@ -230,6 +230,36 @@ def test_c5_at_the_timed_batch_through_the_graph_replayed_train_step(cuda):
     gf.compare_grads(_grads(model, "unet."), gf.GradFixture(fix, "grad:"), what, rule="tryon")
 
 
+def test_warp_forward_on_the_inputs_bench_py_times(cuda):
+    """The warp stage on the benchmark's OWN inputs (c2 / c4 time exactly this): synthetic_batch(4, seed=420, smooth=False).
+    theta (every element) and the TPS grid (1/2 lattice + whole-tensor checksums) of WarpModel's training-mode forward against
+    the REFERENCE's own module (models/warp_model.py:63-72; fixture c2_bench_inputs, fp32_source = "reference"): atol 2e-5 /
+    3e-5 as VERDICT r05 item 8 asks (the grid figure is SURVEY's 1e-5 times the TPS map's ~3.7x amplification of theta's own
+    fp32 noise), and the loss.  No tap flips to excuse here: a forward pass."""
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+
+    fix = gf.load("c2_bench_inputs")
+    assert str(fix["fp32_source"]) == "reference"
+    model, sd = fc.build_warp(cuda)
+    gf.check_digest(fix, "digest:weights", sd)
+    batch_cpu = synthetic_batch(4, "cpu", seed=420, smooth=False)
+    gf.check_digest(fix, "digest:batch", batch_cpu)
+    batch = fc.to_device(batch_cpu, cuda)
+    what = "WarpModel forward, bench inputs"
+    model.train()
+    with torch.no_grad():
+        person = torch.cat([batch[k] for k in fc.WHP["person_inputs"]], 1)
+        cloth = torch.cat([batch[k] for k in fc.WHP["cloth_inputs"]], 1)
+        grid, theta = model(person, cloth)
+    b = theta.shape[0]
+    gf.check_output(fix, "theta", theta.reshape(b, 1, 1, -1), 2e-5, what, mode="fp32")
+    gf.check_output(fix, "grid", grid.permute(0, 3, 1, 2), 3e-5, what, mode="fp32")
+    model2, _ = fc.build_warp(cuda)     # fresh BatchNorm statistics for the training step
+    res = model2.training_step(batch, 0)
+    r = float(fix["log32:loss/G"])
+    assert abs(float(res.minimize) - r) <= 2e-5 + 2e-5 * abs(r), (what, float(res.minimize), r)
+
+
 def test_unet_forward_on_the_inputs_bench_py_times(cuda):
     """The benchmark's OWN inputs: synthetic_batch(4, seed=420, smooth=False) - U(-1, 1) white-noise images, not the
     band-limited images the gradient cases need (those keep grid_sample's tap flips out of the gradients; a forward pass has
