@@ -68,16 +68,19 @@ class GraphedTrainStep:
         self.result = res
 
     def load_batch(self, batch):
-        """Copy a new batch into the static input buffers (device-to-device, same shapes)."""
+        """Copy a new batch into the static input buffers (device-to-device, same shapes): ONE multi-tensor launch."""
+        dst, src = [], []
         for k, v in batch.items():
             if k in self.alias_keys:
                 continue
             if isinstance(v, torch.Tensor):
                 if self.keys is not None and k not in self.keys:
                     continue
-                self.static_batch[k].copy_(v, non_blocking=True)
+                dst.append(self.static_batch[k])
+                src.append(v)
             else:
                 self.static_batch[k] = v
+        _copy_all(dst, src)
 
     def __call__(self, batch=None):
         if batch is not None:
@@ -183,12 +186,15 @@ class GraphedChainedStep:
     @staticmethod
     def _load(dst, batch, keys=None):
         """Copy a new batch into a stage's static buffers; `keys`: only the entries that stage reads."""
+        d, s = [], []
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 if (keys is None or k in keys) and k in dst:
-                    dst[k].copy_(v, non_blocking=True)
+                    d.append(dst[k])
+                    s.append(v)
             else:
                 dst[k] = v
+        _copy_all(d, s)
 
     def launch_warp_forward(self, batch=None):
         """side stream: (load the new batch,) warp forward.  Only waits for the previous step's try-on stage to have taken
@@ -228,6 +234,20 @@ class GraphedChainedStep:
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+def _copy_all(dst, src):
+    """dst[i].copy_(src[i]) for same-shape device tensors as one multi-tensor kernel (a copy per batch entry was 5-9 launches
+    in front of every replayed step); anything the fused form does not take (other device / dtype / layout) is copied singly."""
+    fused = [(d, s) for d, s in zip(dst, src) if s.is_cuda and s.device == d.device and s.dtype == d.dtype and s.shape == d.shape
+             and d.is_contiguous() and s.is_contiguous()]
+    rest = [(d, s) for d, s in zip(dst, src) if not any(d is f[0] for f in fused)]
+    if len(fused) > 1:
+        torch._foreach_copy_([d for d, _ in fused], [s for _, s in fused])
+    else:
+        rest = fused + rest
+    for d, s in rest:
+        d.copy_(s, non_blocking=True)
 
 
 def _side_stream():

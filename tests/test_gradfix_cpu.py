@@ -30,6 +30,10 @@ def test_fixture_loads_and_is_complete(name):
             assert e["s32"] >= 0 and e["own"] >= 0 and e["kink"] >= 0
             assert np.abs(e["g32"]).max() <= e["s32"] * (1 + 1e-6) + 1e-30, k      # samples lie inside the whole-tensor maximum
     assert any(k.startswith("digest:") or ":digest:" in k for k in fix.files)
+    # the fp32 leg of every full-size fixture is the REFERENCE's own evaluation (imported in the build container through
+    # tests/golden/make_golden.py's shim), not the oracle's fp32 pass: try-on / warp cases since round 5, SAMS since round 6
+    src = [str(fix[k]) for k in fix.files if k == "fp32_source" or k.endswith(":fp32_source")]
+    assert src and all(s == "reference" for s in src), (name, src)
 
 
 def test_fixture_digest_matches_the_inputs_the_gpu_tests_rebuild():
