@@ -18,6 +18,15 @@ logger = logging.getLogger("logger")
 
 
 class BaseModel(LightningModule, abc.ABC):
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """nn.Module.load_state_dict, then the derived-weight caches of ops.py are dropped (a load that goes through `.data`
+        leaves `_version` alone; the caches would keep serving transforms of the old weights to gradient-free passes)."""
+        from . import ops
+
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        ops.invalidate_weight_caches()
+        return out
+
     @classmethod
     def modify_commandline_options(cls, parser: argparse.ArgumentParser, is_train):
         parser.add_argument("--person_inputs", nargs="+",

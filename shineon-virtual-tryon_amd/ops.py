@@ -256,11 +256,13 @@ def _ihwo(w_ohwi, owner=None):
     """(O, R, S, C) dense OHWI weights -> (C, R, S, O) transposed copy for the KC x KC input-gradient GEMM.
     owner (for frozen weights): (weakref to the owning parameter, its _version at forward time); the copy is
     cached per parameter OBJECT and version, never per address (addresses are recycled between models)."""
+    if owner is not None and torch.cuda.is_current_stream_capturing():
+        owner = None   # a transform recorded into a graph has not RUN yet: never publish it to (or serve) eager callers
     if owner is not None:
         ref, version = owner
         p = ref()
         hit = _IHWO_CACHE.get(id(p)) if p is not None else None
-        if hit is not None and hit[0]() is p and hit[1] == version and hit[2].shape[0] == w_ohwi.shape[3]:
+        if hit is not None and hit[0]() is p and hit[1] == (version, p.data_ptr()) and hit[2].shape[0] == w_ohwi.shape[3]:
             return hit[2]
     o, r, s, c = w_ohwi.shape
     wt = torch.empty((c, r, s, o), dtype=torch.float32, device=w_ohwi.device)
@@ -269,7 +271,7 @@ def _ihwo(w_ohwi, owner=None):
         dead = [k for k, v in _IHWO_CACHE.items() if v[0]() is None]
         for k in dead:
             del _IHWO_CACHE[k]
-        _IHWO_CACHE[id(owner[0]())] = (owner[0], owner[1], wt)
+        _IHWO_CACHE[id(owner[0]())] = (owner[0], (owner[1], owner[0]().data_ptr()), wt)
     return wt
 
 
@@ -1036,8 +1038,10 @@ def _stacked_qkv(wq, bq, wk, bk, wv, bv):
         return wq, bq
     if any(t.untyped_storage().nbytes() != t.numel() * 4 for t in ws_ + bs_):
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return None    # no cache traffic under capture (the stacked copy would be recorded, not run): the three-GEMM path
     key = tuple(id(t) for t in ws_ + bs_)
-    ver = tuple(t._version for t in ws_ + bs_)
+    ver = tuple((t._version, t.data_ptr()) for t in ws_ + bs_)
     hit = _QKV_CACHE.get(key)
     if hit is not None and all(r() is t for r, t in zip(hit[0], ws_ + bs_)) and hit[1] == ver:
         return hit[2], hit[3]
@@ -1687,6 +1691,9 @@ def _sb16_weights(wk, owner, transpose):
     flipped taps.  Cached per parameter object and version like the transposed fp32 copies."""
     ref, version = owner
     p = ref()
+    if torch.cuda.is_current_stream_capturing():
+        p = None       # see _ihwo: no cache traffic under capture
+    version = (version, p.data_ptr()) if p is not None else version
     key = (id(p), bool(transpose))
     hit = _SB16_W_CACHE.get(key) if p is not None else None
     if hit is not None and hit[0]() is p and hit[1] == version:
@@ -1702,6 +1709,15 @@ def _sb16_weights(wk, owner, transpose):
     return hi, mid
 
 _WINO_W_CACHE = {}
+
+
+def invalidate_weight_caches():
+    """Drop every derived-weight cache (Winograd-domain / transposed / split-bf16 / stacked q-k-v copies of parameters that no
+    gradient is asked of).  The caches follow `Tensor._version` and `data_ptr()`; a write that changes neither - `p.data.copy_`,
+    `dist.broadcast(p.data)`, the reference-style `m.weight.data.normal_()` - needs this call (trainer.broadcast_parameters
+    and BaseModel.load_state_dict make it)."""
+    for c in (_WINO_W_CACHE, _IHWO_CACHE, _SB16_W_CACHE, _QKV_CACHE):
+        c.clear()
 
 
 def _wino_mode(ci, co, n, h, w):
@@ -1733,12 +1749,15 @@ def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None, f44=False):
     L = lib()
     key = None
     numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else (36 if f44 else 16) * ko * c
+    if owner is not None and torch.cuda.is_current_stream_capturing():
+        owner = None   # see _ihwo: a transform recorded into a graph has not run yet - no cache traffic under capture
     if owner is not None:
         ref, version = owner
         p = ref()
+        owner = (ref, (version, p.data_ptr()) if p is not None else version)
         key = (id(p), bool(transpose), bool(fused), bool(f44))
         hit = _WINO_W_CACHE.get(key) if p is not None else None
-        if hit is not None and hit[0]() is p and hit[1] == version and hit[2].numel() == numel:
+        if hit is not None and hit[0]() is p and hit[1] == owner[1] and hit[2].numel() == numel:
             return hit[2]
     u = torch.empty(numel, dtype=torch.float32, device=wk.device)
     fn = L.so_wino_fused_weights if fused else (L.so_wino4_weights if f44 else L.so_wino_weights)

@@ -453,6 +453,7 @@ def broadcast_parameters(model, src=0, optimizer=None):
     else:
         for p in model.parameters():
             dist.broadcast(p.data, src)
+    ops.invalidate_weight_caches()   # the broadcast writes through .data: no version bump for the derived-weight caches to see
     broadcast_buffers(model, src)
 
 

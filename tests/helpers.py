@@ -73,6 +73,8 @@ def assert_grad_samples(get_grad, g, prefix, rel, what="", floor=2e-7, report_ab
         for e, name in sorted(measured, reverse=True):
             print(f"    {e:9.3e}  {name}")
     assert not bad, f"{what}: {len(bad)}/{len(keys)} gradient tensors differ element-wise from the reference: " + "; ".join(bad[:8])
+    if report_above is not None:
+        return len(keys), sorted(measured, reverse=True)
     return len(keys)
 
 

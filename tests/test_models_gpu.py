@@ -70,8 +70,11 @@ def test_warp_model_vs_reference_golden(cuda):
                         what="warp vs reference")
     # (the table of measured per-tensor distances is printed - `pytest -s`, kept in profiles/r06_gpu_tests.log - so the 8e-2
     #  bound is a measured number per tensor: VERDICT r05 item 8 iii)
-    assert_grad_samples(lambda k: params[k].grad, {k: g[k] for k in g.files if "extractionA" in k}, "gs97:", rel=8e-2,
-                        what="warp person branch vs reference", report_above=1e-2)
+    #  Measured in round 6 (profiles/r06_person_branch_gradients.txt): 20 of the 22 tensors are within 5.4e-3, two convolution
+    #  weights (model.15: 3.2e-2, model.2: 1.9e-2) are not - so the bound is 4e-2 with at most two tensors beyond 1e-2.
+    _, measured = assert_grad_samples(lambda k: params[k].grad, {k: g[k] for k in g.files if "extractionA" in k}, "gs97:", rel=4e-2,
+                                      what="warp person branch vs reference", report_above=1e-2)
+    assert sum(1 for e, _ in measured if e > 1e-2) <= 2, measured[:4]
     assert_close(model.extractionA.model[2].running_mean, g["bn_rm_A2"], atol=1e-5, what="BN running mean")
     assert_close(model.extractionA.model[2].running_var, g["bn_rv_A2"], atol=1e-5, what="BN running var")
     assert_close(model.regression.conv[10].running_var, g["bn_rv_R10"], atol=1e-4, what="BN running var R10")

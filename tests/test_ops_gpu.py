@@ -416,6 +416,85 @@ def test_self_attention(ops, cuda, hw):
                      what=f"self_attention forward-only after an in-place weight update {hw}")
 
 
+def test_forward_only_weight_caches_follow_the_parameters(ops, cuda):
+    """The gradient-free conv2d path caches the Winograd-domain weights of a stand-alone parameter per (object, version,
+    address): an optimizer step (version bump) must be seen, a write through `.data` (no bump) needs
+    ops.invalidate_weight_caches(), and nothing may be cached or served while a stream captures."""
+    x = rnd(4, 128, 32, 24, seed=90).to(cuda)      # 3072 pixels x 128 channels: the non-fused Winograd form (ops._wino_mode)
+    w = torch.nn.Parameter(rnd(128, 128, 3, 3, seed=91, scale=0.05).to(cuda))
+    b = torch.nn.Parameter(rnd(128, seed=92, scale=0.1).to(cuda))
+    assert ops._wino_mode(128, 128, 4, 32, 24) != "direct"
+
+    def fresh():
+        ops.invalidate_weight_caches()
+        with torch.no_grad():
+            return ops.to_nchw(ops.conv2d(x, w, b, 1, 1)).clone()
+
+    with torch.no_grad():
+        y0 = ops.to_nchw(ops.conv2d(x, w, b, 1, 1)).clone()
+        assert ops._WINO_W_CACHE, "the forward-only Winograd path did not run / cache"
+        assert torch.equal(ops.to_nchw(ops.conv2d(x, w, b, 1, 1)), y0)            # cache hit
+    opt = torch.optim.SGD([w, b], lr=0.5)
+    w.grad, b.grad = torch.ones_like(w), torch.ones_like(b)
+    opt.step()                                                                       # in-place update: version bump
+    with torch.no_grad():
+        y1 = ops.to_nchw(ops.conv2d(x, w, b, 1, 1)).clone()
+    assert not torch.equal(y1, y0) and torch.equal(y1, fresh())
+    w.data.mul_(0.5)                                                                 # through .data: no version bump
+    with torch.no_grad():
+        stale = ops.to_nchw(ops.conv2d(x, w, b, 1, 1)).clone()
+    y2 = fresh()
+    assert not torch.equal(y2, y1)
+    assert torch.equal(stale, y1), "expected the documented stale hit without invalidate_weight_caches()"
+    # under capture: neither populated nor served
+    ops.invalidate_weight_caches()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        yc = ops.conv2d(x, w, b, 1, 1)
+    assert not ops._WINO_W_CACHE, "a transform recorded into a graph was published to the cache"
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ops.to_nchw(yc), y2)
+
+
+@pytest.mark.parametrize("n_keep", [0, 2, 4])
+def test_winograd_fused_conv_with_pooling_epilogue(ops, cuda, n_keep):
+    """so_wino_fused_conv3x3_pool (VGG conv1_2 / conv2_2, vgg.py:14-25): conv + bias + ReLU with MaxPool2d(2, 2) written by the
+    epilogue, y stored for the first n_keep images only (y may be NULL for n_keep = 0), a pooled pitch wider than Ko, ragged
+    Ko; odd H or W is refused.  Against an fp64 convolution."""
+    L = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nb, h, w, c, ko, ldyp = 4, 16, 24, 32, 40, 48
+    x = rnd(nb, c, h, w, seed=95)
+    wt = rnd(ko, c, 3, 3, seed=96, scale=(2.0 / (9 * c)) ** 0.5)
+    bias = rnd(ko, seed=97, scale=0.1)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+    ref_pool = F.max_pool2d(ref, 2, 2)
+    xr = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    w_ohwi = wt.permute(0, 2, 3, 1).contiguous().to(cuda)
+    u = torch.empty(L.so_wino_fused_weight_floats(ko, c, 0), device=cuda)
+    assert L.so_wino_fused_weights(w_ohwi.data_ptr(), u.data_ptr(), ko, ko, c, 0, st) == 0
+    y = torch.full((nb, h, w, ko), float("nan"), device=cuda)
+    yp = torch.full((nb, h // 2, w // 2, ldyp), float("nan"), device=cuda)
+    bdev = bias.to(cuda)
+    rc = L.so_wino_fused_conv3x3_pool(xr.data_ptr(), c, u.data_ptr(), bdev.data_ptr(), ko, y.data_ptr() if n_keep else None, ko,
+                                      n_keep, yp.data_ptr(), ldyp, nb, h, w, c, ko, 1, 0.0, st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got_pool = yp[..., :ko].permute(0, 3, 1, 2).cpu().double()
+    assert (got_pool - ref_pool).abs().max().item() < 2e-5
+    assert torch.isnan(yp[..., ko:]).all(), "the pad columns of the pooled map were written"
+    if n_keep:
+        got = y[:n_keep].permute(0, 3, 1, 2).cpu().double()
+        assert (got - ref[:n_keep]).abs().max().item() < 2e-5
+        # the pooled map is exactly the maximum of the stored activations
+        assert torch.equal(F.max_pool2d(y[:n_keep].permute(0, 3, 1, 2), 2, 2), yp[:n_keep, ..., :ko].permute(0, 3, 1, 2))
+    assert torch.isnan(y[n_keep:]).all(), "activations beyond n_keep were stored"
+    for hh, ww in ((15, 24), (16, 23)):
+        assert L.so_wino_fused_conv3x3_pool(xr.data_ptr(), c, u.data_ptr(), bdev.data_ptr(), ko, y.data_ptr(), ko, nb, yp.data_ptr(),
+                                            ldyp, nb, hh, ww, c, ko, 1, 0.0, st) == -2     # SO_ERR_SHAPE
+
+
 # ------------------------------------------------------------------------------------------------ GMM
 def test_l2norm_correlation(ops, cuda):
     fa, fb = rnd(2, 32, 16, 12, seed=30), rnd(2, 32, 16, 12, seed=31)
