@@ -122,17 +122,6 @@ int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const fl
 /* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
-/* Grouped ("pair") convolutions: the GMM's two feature-extraction towers (warp.py:9-36, warp_model.py:45-53) run identical
- * layer shapes on different inputs with different weights - ONE launch for both.  x / y / dy / dx: [2 Nb][H][W][ld], tower 0's Nb
- * images first; weights, biases and gradient destinations: two 16-byte-aligned pointers each.  Same arithmetic per tower as the
- * single entry points (fprop / dgrad with in-place OHWI weights / wgrad accumulating into the gradient slab). */
-int so_conv2d_fprop_pair(const float* x, int ldx, const float* w0, const float* w1, const float* bias0, const float* bias1,
-                         float* y, int ldy, int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
-                         float act_param, float* ws, long long ws_bytes, void* stream);
-int so_conv2d_dgrad_pair(const float* dy, int lddy, const float* w0, const float* w1, float* dx, int lddx, int Nb, int H, int W,
-                         int C, int Ko, int R, int S, int stride, int pad, float* ws, long long ws_bytes, void* stream);
-int so_conv2d_wgrad_acc_pair(const float* dy, int lddy, const float* x, int ldx, float* dw0, float* dw1, int Nb, int H, int W,
-                             int C, int Ko, int R, int S, int stride, int pad, float* ws, long long ws_bytes, void* stream);
 /* csrc/attn.hip: SAGAN self-attention core for n = H*W <= 256 positions (sagan.py:38-52) on qkv = [q | k | v] rows ([B n][E], the
  * output of ONE projection GEMM).  so_attn_supported: 1 when the fused kernels take the shape (C % 32 == 0, d % 4 == 0, LDS fits);
  * so_attn_fwd: energy -> softmax -> attention x V -> gamma * o + x in one launch (a: [B][n][n], o: [B n][C], both may be NULL);
@@ -228,17 +217,6 @@ int so_norm_bwd_bias(const float* x, int ldx, const float* dy, int lddy, float* 
                      long long R, int C, const float* mean, const float* rstd, const float* gamma,
                      float* dgamma, float* dbeta, int accumulate, int relu_gate, float* dbias, int accumulate_bias,
                      float* ws, void* stream);
-
-/* Pair launches: the BatchNorms of the GMM's two feature-extraction towers (warp.py:9-36) as ONE launch - rows of tower 0, then
- * of tower 1 (R each); every per-channel tensor is two pointers; mean / rstd: [2][C].  Per tower the arithmetic of so_norm_fwd /
- * so_norm_bwd / so_norm_bwd_bias with G = 1. */
-int so_norm_fwd_pair(const float* x, int ldx, float* y, int ldy, long long R, int C, float eps, const float* gamma0,
-                     const float* beta0, const float* gamma1, const float* beta1, float* mean, float* rstd, float* rm0, float* rv0,
-                     float* rm1, float* rv1, float momentum, float* ws, void* stream);
-int so_norm_bwd_pair(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long R, int C,
-                     const float* mean, const float* rstd, const float* gamma0, const float* gamma1, float* dgamma0, float* dbeta0,
-                     float* dgamma1, float* dbeta1, int accumulate, int relu_gate, float* dbias0, float* dbias1,
-                     int accumulate_bias, float* ws, void* stream);
 
 /* ---- pointwise / resampling / reductions (csrc/elementwise.hip) ---------------------------------- */
 

@@ -59,12 +59,6 @@ struct SoIgemm {
   int splitk, ktps, nclass;
   int nbias;         // bias entries available (columns >= nbias get no bias: zero channel padding)
   long long sa, sb, sc, sres;  // GEMM batch strides in elements
-  // Conv modes, ngroup > 1 (round 6): the SAME problem for `ngroup` independent operand sets in one launch - the two feature-
-  // extraction towers of the GMM (warp.py:9-36, warp_model.py:45-53) have identical layer shapes and different weights.
-  // Group g reads a + g * ga, b + g * gb, bias + g * gbias, res + g * gres and writes c + g * gc (element strides; the
-  // tower weights are plain pointer differences inside the optimizer's slab).  Grid z = group x class x split.
-  int ngroup;
-  long long ga, gb, gc, gres, gbias;
 };
 
 // pins memory ops (global, LDS) and MFMAs in source order; VALU/SALU address arithmetic may float across
@@ -92,10 +86,10 @@ __device__ __forceinline__ float so_act_epi(const SoIgemm& p, float v) {
   return (p.act == SO_ACT_NONE || v > 0.f) ? v : (p.act == SO_ACT_RELU ? 0.f : v * p.act_param);
 }
 
-__device__ __forceinline__ float so_epilogue(const SoIgemm& p, const float* bias, const float* res, float v, long long res_off, int n) {
+__device__ __forceinline__ float so_epilogue(const SoIgemm& p, float v, long long res_off, int n) {
   if (p.alpha) v *= p.alpha[0];
-  if (bias && n < p.nbias) v += bias[n];
-  if (res) v += res[res_off + n];
+  if (p.bias && n < p.nbias) v += p.bias[n];
+  if (p.res) v += p.res[res_off + n];
   return so_act_epi(p, v);
 }
 
@@ -201,8 +195,7 @@ __device__ __forceinline__ int so_swz(int row) {
 // NW = waves per block: 4 (2x2 wave grid) or 8 (2x4, BN = 128 only: twice the waves per SIMD for the same LDS
 // footprint, which hides the staging bubbles of the large tiles).
 template <int MODE, bool A_MC, bool B_MC, int BM, int BN, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm pin) {
-  SoIgemm p = pin;   // block-uniform (SGPRs); the group offsets of a grouped launch are folded into its pointers below
+__global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm p) {
   constexpr int BK = 32;
   constexpr int NT = NW * 64;
   constexpr int LDK = 36;  // row pitch of the epilogue's wave-private transposition patches
@@ -251,19 +244,8 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm pin)
   const int tile_m = bx / tiles_n;
   const int tile_n = bx - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int bzz = bz;   // (class, split) index within the group
-  if (p.ngroup > 1) {
-    const int zper = p.nclass * p.splitk;
-    const int grp = bz / zper;
-    bzz = bz - grp * zper;
-    p.a += (long long)grp * p.ga;
-    p.b += (long long)grp * p.gb;
-    p.c += (long long)grp * p.gc;
-    if (p.res) p.res += (long long)grp * p.gres;
-    if (p.bias) p.bias += (long long)grp * p.gbias;
-  }
-  const int cls = bzz / p.splitk;
-  const int split = bzz - cls * p.splitk;
+  const int cls = bz / p.splitk;
+  const int split = bz - cls * p.splitk;
 
   const float* gA = p.a;
   const float* gB = p.b;
@@ -834,7 +816,7 @@ __global__ __launch_bounds__(NW * 64, 2) void so_igemm_kernel(const SoIgemm pin)
         for (int j = 0; j < TN; ++j) {
           const int n = n0 + wn * WTN + j * 32 + li;
           if (n < p.N) {
-            const float e = so_epilogue(p, p.bias, p.res, acc[i][j][r], roff, n);
+            const float e = so_epilogue(p, acc[i][j][r], roff, n);
             p.c[off + n] = (!p.gate || p.gate[off + n] > 0.f) ? e : 0.f;
           }
         }
@@ -850,29 +832,24 @@ template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   const long long mn = (long long)p.M * p.N;
-  const int ng = p.ngroup > 1 ? p.ngroup : 1;
-  const long long total = (long long)ng * p.nclass * mn / VEC;
+  const long long total = (long long)p.nclass * mn / VEC;
   const int nq = p.N / VEC;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * 256) {
-    const int clsf = (int)(idx / (mn / VEC));           // group * nclass + class: the slab order of the main kernel's grid z
-    const long long remq = idx - (long long)clsf * (mn / VEC);
-    const int grp = clsf / p.nclass, cls = clsf - grp * p.nclass;
+    const int cls = (int)(idx / (mn / VEC));
+    const long long remq = idx - (long long)cls * (mn / VEC);
     const int m = (int)(remq / nq);
     const int n = (int)(remq - (long long)m * nq) * VEC;
-    const float* src = p.ws + (long long)clsf * p.splitk * mn + (long long)m * p.N + n;
+    const float* src = p.ws + (long long)cls * p.splitk * mn + (long long)m * p.N + n;
     vec_t v = so_sum_slabs<vec_t>(src, p.splitk, mn);
     long long off, roff;
     so_row_offset<MODE>(p, cls, m, off, roff);
     if (off < 0) continue;
-    off += (long long)grp * p.gc;
-    roff += (long long)grp * p.gres;
-    const float* bias = p.bias ? p.bias + (long long)grp * p.gbias : nullptr;
     if constexpr (VEC == 4) {
       if (p.alpha) v *= p.alpha[0];
-      if (bias) {
+      if (p.bias) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (n + k < p.nbias) v[k] += bias[n + k];
+        for (int k = 0; k < 4; ++k) if (n + k < p.nbias) v[k] += p.bias[n + k];
       }
       if (p.res) v += *reinterpret_cast<const vec_t*>(p.res + roff + n);
       if (p.act != SO_ACT_NONE) {
@@ -886,7 +863,7 @@ __global__ __launch_bounds__(256) void so_splitk_reduce_kernel(const SoIgemm p) 
       }
       *reinterpret_cast<vec_t*>(p.c + off + n) = v;
     } else {
-      const float e = so_epilogue(p, bias, p.res, v[0], roff, n);
+      const float e = so_epilogue(p, v[0], roff, n);
       p.c[off + n] = (!p.gate || p.gate[off + n] > 0.f) ? e : 0.f;
     }
   }
@@ -916,19 +893,18 @@ static SoPlan so_plan(const SoIgemm& p, long long ws_floats) {
   for (int ti = 0; ti < kNTiles; ++ti) {
     const int bm = kTiles[ti][0], bn = kTiles[ti][1], nw = kTiles[ti][2];
     if (g_force_bm && (bm != g_force_bm || bn != g_force_bn || nw != (g_force_nw ? g_force_nw : 4))) continue;
-    const int ng = p.ngroup > 1 ? p.ngroup : 1;
-    const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bn) * p.nclass * ng;
+    const long long tiles = (long long)so_cdiv(p.M, bm) * so_cdiv(p.N, bn) * p.nclass;
     for (int sk = 1; sk <= 512; sk *= 2) {
       if (g_force_splitk && sk != g_force_splitk) continue;
       if (sk > nkt) break;
       const int ktps = so_cdiv(nkt, sk);
       const int sk_eff = so_cdiv(nkt, ktps);
-      if (sk_eff > 1 && (long long)sk_eff * ng * p.nclass * p.M * p.N > ws_floats) continue;
+      if (sk_eff > 1 && (long long)sk_eff * p.nclass * p.M * p.N > ws_floats) continue;
       const long long blocks = tiles * sk_eff;
       const double t_kt = 2.0 * bm * bn * 32 / (0.6e12 * 0.8) * g_tile_cost[ti];
       const double waves = (double)((blocks + 255) / 256);
       double cost = waves * (ktps + 3) * t_kt;
-      if (sk_eff > 1) cost += 3e-6 + (double)(sk_eff + 1) * ng * p.nclass * p.M * p.N * 4.0 / 3e12;
+      if (sk_eff > 1) cost += 3e-6 + (double)(sk_eff + 1) * p.nclass * p.M * p.N * 4.0 / 3e12;
       if (cost < best_cost) {
         best_cost = cost;
         best = {bm, bn, sk_eff, ktps, nw};
@@ -1001,11 +977,9 @@ static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
     attr_set = true;
   }
   const long long tiles = (long long)so_cdiv(p.M, BM) * so_cdiv(p.N, BN);
-  const int ng = p.ngroup > 1 ? p.ngroup : 1;
-  dim3 grid((unsigned)tiles, 1, (unsigned)(ng * p.nclass * p.splitk));
+  dim3 grid((unsigned)tiles, 1, (unsigned)(p.nclass * p.splitk));
   // split-K: 16-byte epilogue possible?  (the slabs themselves are always written wide when N % 4 == 0)
   const bool wide = (p.N & 3) == 0 && (p.ldc & 3) == 0 && so_aligned16(p.c) && so_aligned16(p.ws) &&
-                    (ng == 1 || (((p.gc | p.gres) & 3) == 0)) &&
                     (MODE != MODE_GEMM || (p.sc & 3) == 0) &&
                     (!p.res || ((p.ldres & 3) == 0 && so_aligned16(p.res) && (MODE != MODE_GEMM || (p.sres & 3) == 0))) &&
                     (!p.gate || so_aligned16(p.gate));
@@ -1021,12 +995,12 @@ static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
     // batched GEMMs with >= 16 matrices are the Winograd-domain GEMMs of csrc/wino.hip (16 or 36 transform points): their own
     // key group (4), so that they are not averaged with the ~10 us attention GEMMs that share the 64x64 instantiation
     if (MODE == MODE_GEMM && p.nclass >= 16) rec.key += 8;
-    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass * ng;
+    rec.flops = 2.0 * p.M * p.N * (double)p.K * p.nclass;
     // convolution modes (fprop / dgrad / wgrad alike): the input-side tensor, the output-side tensor and the filter, each
     // touched once; batched GEMM: A, B and C of every matrix
     rec.bytes = MODE == MODE_GEMM
                     ? 4.0 * p.nclass * ((double)p.M * p.K + (double)p.K * p.N + (double)p.M * p.N)
-                    : 4.0 * ng * ((double)p.Nb * p.H * p.W * p.C + (double)p.Nb * p.Ho * p.Wo * p.Ko + (double)p.Ko * p.R * p.S * p.C);
+                    : 4.0 * ((double)p.Nb * p.H * p.W * p.C + (double)p.Nb * p.Ho * p.Wo * p.Ko + (double)p.Ko * p.R * p.S * p.C);
     rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.nclass = p.nclass; rec.splitk = p.splitk;
     (void)hipEventRecord(rec.e0, stream);
   }
@@ -1038,7 +1012,7 @@ static int so_launch_tile(const SoIgemm& p_in, hipStream_t stream) {
   int err = SO_LAUNCH_CHECK();
   if (err) return err;
   if (p.splitk > 1) {
-    const long long total = (long long)ng * p.nclass * p.M * p.N;
+    const long long total = (long long)p.nclass * p.M * p.N;
     int blocks = so_cdiv(wide ? total / 4 : total, 256);
     if (blocks > 4096) blocks = 4096;
     if (wide)
@@ -1083,7 +1057,7 @@ static int so_launch(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   const int act = p.act;
   const bool deferred = act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY;
   if (deferred) {
-    if (p.gate || p.ngroup > 1 || (MODE != MODE_FPROP && MODE != MODE_GEMM)) return SO_ERR_SHAPE;
+    if (p.gate || (MODE != MODE_FPROP && MODE != MODE_GEMM)) return SO_ERR_SHAPE;
     p.act = SO_ACT_NONE;
   }
   const int err = so_launch_inner<MODE, A_MC, B_MC>(p, ws_bytes, stream);
@@ -1104,12 +1078,10 @@ static int so_launch_inner(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return 0;
   const long long ws_floats = p.ws ? ws_bytes / 4 : 0;
   if (g_force_bm || g_force_splitk || !g_autotune) return so_launch_plan<MODE, A_MC, B_MC>(p, so_plan(p, ws_floats), stream);
-  const int ng = p.ngroup > 1 ? p.ngroup : 1;
-  // (grouped launches are shapes of their own: twice the tiles per launch, other split-K optima; ng = 1 keeps the round-5 keys)
-  const std::array<int, 12> key = {MODE, (int)A_MC * 2 + (int)B_MC + 4 * (ng - 1), p.M, p.N, p.K, p.nclass, p.R, p.S, p.stride, p.C,
-                                   p.Ko, p.lda * 31 + p.ldb};
+  const std::array<int, 12> key = {MODE, (int)A_MC * 2 + (int)B_MC, p.M, p.N, p.K, p.nclass, p.R, p.S, p.stride, p.C, p.Ko,
+                                   p.lda * 31 + p.ldb};
   auto it = g_plan_cache.find(key);
-  const long long mn = (long long)ng * p.nclass * p.M * p.N;
+  const long long mn = (long long)p.nclass * p.M * p.N;
   if (it != g_plan_cache.end()) {
     // a cached / loaded plan was measured against some workspace: re-check its slab requirement against the
     // workspace actually handed in (a plans file from another configuration must never overrun the slab)
@@ -1136,8 +1108,6 @@ static int so_launch_inner(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
   SoIgemm q = p;
   q.res = nullptr;
   q.ldres = 0;
-  q.gres = 0;
-  if (!(MODE == MODE_DGRAD && p.nclass > 1)) q.gc = (long long)p.nclass * p.M * p.N;   // dense scratch output per group
   int err = 0;
   const int timed_reps = g_autotune >= 2 ? 6 : 2;
   if (g_autotune >= 2) {
@@ -1171,7 +1141,7 @@ static int so_launch_inner(SoIgemm& p, long long ws_bytes, hipStream_t stream) {
       if (ktps == last_ktps) continue;                          // same plan as the previous power of two
       last_ktps = ktps;
       if ((long long)(sk_eff > 1 ? sk_eff : 0) * mn + mn > ws_floats) continue;
-      const long long blocks = (long long)so_cdiv(p.M, kTiles[ti][0]) * so_cdiv(p.N, kTiles[ti][1]) * p.nclass * ng * sk_eff;
+      const long long blocks = (long long)so_cdiv(p.M, kTiles[ti][0]) * so_cdiv(p.N, kTiles[ti][1]) * p.nclass * sk_eff;
       if (blocks > 65536 || (sk_eff > 1 && blocks > 8192)) continue;
       SoPlan cand = {kTiles[ti][0], kTiles[ti][1], sk_eff, ktps, kTiles[ti][2]};
       q.c = p.ws + (long long)(sk_eff > 1 ? sk_eff : 0) * mn;   // scratch output behind the slabs
@@ -1453,85 +1423,6 @@ int so_conv2d_wgrad_acc(const float* dy, int lddy, const float* x, int ldx, floa
   p.b_bytes = so_extent((long long)Nb * H * W, ldx);
   if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24)) return SO_ERR_SHAPE;
   p.act = SO_ACT_NONE; p.nclass = 1;
-  return so_launch<MODE_WGRAD, true, true>(p, ws_bytes, (hipStream_t)stream);
-}
-
-// ---- grouped ("pair") convolutions: two operand sets with identical shapes in ONE launch -------------------------------
-// The GMM's two feature-extraction towers (models/networks/cpvton/warp.py:9-36, built twice at models/warp_model.py:45-53) run
-// the same layer shapes on different inputs with different weights.  x / y / dy / dx hold both towers' images back to back
-// ([2 Nb][H][W][ld]: tower 0's Nb images, then tower 1's); weights, biases and gradient destinations are two pointers each
-// (any two 16-byte-aligned addresses: the towers' parameters are views of one optimizer slab).  Twice the tiles per launch:
-// half the launches of the warp stage's largest block of work, and split-K factors chosen for a fuller chip.
-static long long so_pdiff(const float* p1, const float* p0) { return (long long)(p1 - p0); }
-
-int so_conv2d_fprop_pair(const float* x, int ldx, const float* w0, const float* w1, const float* bias0, const float* bias1,
-                         float* y, int ldy, int Nb, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int act,
-                         float act_param, float* ws, long long ws_bytes, void* stream) {
-  if ((C & 3) || (Ko & 3) || (ldx & 3) || (ldy & 3) || !so_aligned16(x) || !so_aligned16(w0) || !so_aligned16(w1) || !so_aligned16(y))
-    return SO_ERR_ALIGN;
-  if ((bias0 == nullptr) != (bias1 == nullptr)) return SO_ERR_SHAPE;
-  SoIgemm p = {};
-  p.a = x; p.b = w0; p.c = y; p.ws = ws; p.bias = bias0; p.nbias = Ko;
-  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
-  p.Ho = (H + 2 * pad - R) / stride + 1;
-  p.Wo = (W + 2 * pad - S) / stride + 1;
-  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.M = Nb * p.Ho * p.Wo; p.N = Ko; p.K = R * S * C;
-  p.lda = ldx; p.ldb = p.K; p.ldc = ldy; p.ldres = 0;
-  p.a_bytes = so_extent((long long)Nb * H * W, ldx);
-  p.b_bytes = so_extent(Ko, p.K);
-  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
-  p.act = act; p.act_param = act_param; p.nclass = 1;
-  p.ngroup = 2;
-  p.ga = (long long)Nb * H * W * ldx; p.gb = so_pdiff(w1, w0); p.gc = (long long)p.M * ldy;
-  p.gbias = bias0 ? so_pdiff(bias1, bias0) : 0;
-  return so_launch<MODE_FPROP, false, false>(p, ws_bytes, (hipStream_t)stream);
-}
-
-// input gradients of both towers, OHWI weights read in place (so_conv2d_dgrad)
-int so_conv2d_dgrad_pair(const float* dy, int lddy, const float* w0, const float* w1, float* dx, int lddx, int Nb, int H, int W,
-                         int C, int Ko, int R, int S, int stride, int pad, float* ws, long long ws_bytes, void* stream) {
-  if ((Ko & 3) || (lddy & 3) || (C & 3) || (lddx & 3) || !so_aligned16(dy) || !so_aligned16(w0) || !so_aligned16(w1) || !so_aligned16(dx))
-    return SO_ERR_ALIGN;
-  if ((R % stride) || (S % stride)) return SO_ERR_SHAPE;
-  SoIgemm p = {};
-  p.a = dy; p.b = w0; p.c = dx; p.ws = ws;
-  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
-  p.Ho = (H + 2 * pad - R) / stride + 1;
-  p.Wo = (W + 2 * pad - S) / stride + 1;
-  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.TS = S / stride; p.H2 = (H + stride - 1) / stride; p.W2 = (W + stride - 1) / stride;
-  p.nclass = stride * stride;
-  p.M = Nb * p.H2 * p.W2; p.N = C; p.K = (R / stride) * (S / stride) * Ko;
-  p.lda = lddy; p.ldb = C; p.ldc = lddx; p.ldres = 0;
-  p.a_bytes = so_extent((long long)Nb * p.Ho * p.Wo, lddy);
-  p.b_bytes = so_extent((long long)Ko * R * S, C);
-  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24) || p.M >= (1 << 24)) return SO_ERR_SHAPE;
-  p.act = SO_ACT_NONE;
-  p.ngroup = 2;
-  p.ga = (long long)Nb * p.Ho * p.Wo * lddy; p.gb = so_pdiff(w1, w0); p.gc = (long long)Nb * H * W * lddx;
-  return so_launch<MODE_DGRAD, false, true>(p, ws_bytes, (hipStream_t)stream);
-}
-
-// dw0 += / dw1 += the towers' weight gradients (so_conv2d_wgrad_acc), straight into the gradient slab
-int so_conv2d_wgrad_acc_pair(const float* dy, int lddy, const float* x, int ldx, float* dw0, float* dw1, int Nb, int H, int W,
-                             int C, int Ko, int R, int S, int stride, int pad, float* ws, long long ws_bytes, void* stream) {
-  if ((Ko & 3) || (lddy & 3) || (C & 3) || (ldx & 3) || !so_aligned16(dy) || !so_aligned16(x) || !so_aligned16(dw0) || !so_aligned16(dw1))
-    return SO_ERR_ALIGN;
-  SoIgemm p = {};
-  p.a = dy; p.b = x; p.c = dw0; p.ws = ws; p.res = dw0;
-  p.Nb = Nb; p.H = H; p.W = W; p.C = C;
-  p.Ho = (H + 2 * pad - R) / stride + 1;
-  p.Wo = (W + 2 * pad - S) / stride + 1;
-  p.Ko = Ko; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.M = Ko; p.N = R * S * C; p.K = Nb * p.Ho * p.Wo;
-  p.lda = lddy; p.ldb = ldx; p.ldc = p.N; p.ldres = p.N;
-  p.a_bytes = so_extent(p.K, lddy);
-  p.b_bytes = so_extent((long long)Nb * H * W, ldx);
-  if (!p.a_bytes || !p.b_bytes || p.K >= (1 << 24)) return SO_ERR_SHAPE;
-  p.act = SO_ACT_NONE; p.nclass = 1;
-  p.ngroup = 2;
-  p.ga = (long long)p.K * lddy; p.gb = (long long)Nb * H * W * ldx; p.gc = so_pdiff(dw1, dw0); p.gres = p.gc;
   return so_launch<MODE_WGRAD, true, true>(p, ws_bytes, (hipStream_t)stream);
 }
 

@@ -31,12 +31,6 @@ __device__ __forceinline__ Mom mom_merge(Mom a, Mom b) {
   return r;
 }
 
-// Element offsets of statistics domain g's own tensors (pair launches, round 6: the two BatchNorms of the GMM's twin towers run
-// as ONE launch with G = 2 - domain g uses gamma + g * gamma etc.; plain launches pass zeros).
-struct NormGrp {
-  long long gamma, beta, rm, rv, dgamma, dbeta, dbias;
-};
-
 constexpr int EPT = 8;   // rows per thread per chunk (at least)
 
 // part layout: [G][nchunk][3][C]
@@ -89,7 +83,7 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
                                                      unsigned C, float eps, float* __restrict__ mean,
                                                      float* __restrict__ rstd,
                                                      float* __restrict__ running_mean,
-                                                     float* __restrict__ running_var, float momentum, const NormGrp grp) {
+                                                     float* __restrict__ running_var, float momentum) {
   // 16 columns x 64 chunk-lanes per block: lane l merges chunks l, l+64, ... then the lanes are merged in
   // a fixed order through LDS (deterministic).
   __shared__ float sn[1024], sm[1024], s2[1024];
@@ -122,10 +116,8 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
   rstd[(size_t)g * C + c] = 1.0f / sqrtf(var + eps);
   if (running_mean) {
     const float unbiased = acc.n > 1.f ? acc.m2 / (acc.n - 1.f) : var;
-    float* rm = running_mean + (long long)g * grp.rm;
-    float* rv = running_var + (long long)g * grp.rv;
-    rm[c] = (1.f - momentum) * rm[c] + momentum * acc.mean;
-    rv[c] = (1.f - momentum) * rv[c] + momentum * unbiased;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * acc.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
 }
 
@@ -140,7 +132,7 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, int stat_is_var,
                                                     float eps, float* __restrict__ y2, int ldy2, int act2,
-                                                    float act2_param, const NormGrp grp) {
+                                                    float act2_param) {
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
@@ -157,7 +149,7 @@ __global__ __launch_bounds__(256) void norm_apply_k(const float* __restrict__ x,
       float r = rs[i];
       if (stat_is_var) r = 1.0f / sqrtf(r + eps);
       float v = (xv[i] - mu[i]) * r;
-      if (gamma) v = v * gamma[(long long)g * grp.gamma + c0 + i] + beta[(long long)g * grp.beta + c0 + i];
+      if (gamma) v = v * gamma[c0 + i] + beta[c0 + i];
       o[i] = v;
     }
     *reinterpret_cast<vec_t*>(y + (size_t)row * ldy + c0) = o;
@@ -236,8 +228,7 @@ __global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict
                                                         float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int accumulate,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                        float invR, float* __restrict__ dbias, int accumulate_bias,
-                                                        const NormGrp grp) {
+                                                        float invR, float* __restrict__ dbias, int accumulate_bias) {
   constexpr int NS = GATED ? 5 : 2;
   __shared__ float sa[NS][1024];
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -267,18 +258,14 @@ __global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict
   sums[(size_t)g * 2 * C + c] = a[0];
   sums[(size_t)g * 2 * C + C + c] = a[1];
   if (dgamma) {
-    float* dg = dgamma + (long long)g * grp.dgamma;
-    float* db = dbeta + (long long)g * grp.dbeta;
-    dg[c] = (accumulate ? dg[c] : 0.f) + a[1];
-    db[c] = (accumulate ? db[c] : 0.f) + a[0];
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + a[1];
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + a[0];
   }
   if constexpr (GATED) {
-    if (dbias) {   // batch statistics: one domain per affine set
-      const float rs = rstd[(size_t)g * C + c];
-      const float sc = gamma ? rs * gamma[(long long)g * grp.gamma + c] : rs;
+    if (dbias) {   // G == 1
+      const float sc = gamma ? rstd[c] * gamma[c] : rstd[c];
       const float v = sc * (a[2] - a[0] * invR * a[3] - a[1] * invR * a[4]);
-      float* dbi = dbias + (long long)g * grp.dbias;
-      dbi[c] = (accumulate_bias ? dbi[c] : 0.f) + v;
+      dbias[c] = (accumulate_bias ? dbias[c] : 0.f) + v;
     }
   }
 }
@@ -292,7 +279,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ sums, int relu_gate, const NormGrp grp) {
+                                                        const float* __restrict__ sums, int relu_gate) {
   const unsigned CQ = C / VEC;
   const unsigned total = G * R * CQ;
   const float invR = 1.0f / (float)R;
@@ -313,7 +300,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_k(const float* __restrict_
       const float xh = (xq[i] - mq[i]) * rq[i];
       float v = dq[i] - s1q[i] * invR - xh * s2q[i] * invR;
       v *= rq[i];
-      if (gamma) v *= gamma[(long long)g * grp.gamma + c0 + i];
+      if (gamma) v *= gamma[c0 + i];
       if (relu_gate && !(xq[i] > 0.f)) v = 0.f;  // x is a ReLU output: also chain through that ReLU
       o[i] = v;
     }
@@ -335,8 +322,7 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                          float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float momentum,
-                                                         float* __restrict__ y2, int ldy2, int act2, float act2_param,
-                                                         const NormGrp grp) {
+                                                         float* __restrict__ y2, int ldy2, int act2, float act2_param) {
   __shared__ float sn[32][33], sm[32][33], s2[32][33];
   __shared__ float bmean[32], brstd[32];
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -380,16 +366,14 @@ __global__ __launch_bounds__(1024) void norm_small_fwd_k(const float* __restrict
     bmean[tx] = acc.mean; brstd[tx] = rs;
     if (running_mean) {
       const float unbiased = acc.n > 1.f ? acc.m2 / (acc.n - 1.f) : var;
-      float* rm = running_mean + (long long)g * grp.rm;
-      float* rv = running_var + (long long)g * grp.rv;
-      rm[col] = (1.f - momentum) * rm[col] + momentum * acc.mean;
-      rv[col] = (1.f - momentum) * rv[col] + momentum * unbiased;
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * acc.mean;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
     }
   }
   __syncthreads();
   if (!live || !y) return;  // y == nullptr: statistics only
   const float m = bmean[tx], rs = brstd[tx];
-  const float ga = gamma ? gamma[(long long)g * grp.gamma + col] : 1.f, be = gamma ? beta[(long long)g * grp.beta + col] : 0.f;
+  const float ga = gamma ? gamma[col] : 1.f, be = gamma ? beta[col] : 0.f;
   float* by = y + (size_t)g * R * ldy + col;
 #pragma unroll 8
   for (unsigned r = ty; r < R; r += 32) {
@@ -406,7 +390,7 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, int accumulate, int relu_gate,
-                                                         float* __restrict__ dbias, int accumulate_bias, const NormGrp grp) {
+                                                         float* __restrict__ dbias, int accumulate_bias) {
   __shared__ float p1[32][33], p2[32][33];
   __shared__ float b1[32], b2[32];
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -432,17 +416,15 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
     for (unsigned l = 0; l < 32; ++l) { a += p1[l][tx]; b += p2[l][tx]; }
     b1[tx] = a; b2[tx] = b;
     if (dgamma) {
-      float* dg = dgamma + (long long)g * grp.dgamma;
-      float* db = dbeta + (long long)g * grp.dbeta;
-      dg[col] = (accumulate ? dg[col] : 0.f) + b;
-      db[col] = (accumulate ? db[col] : 0.f) + a;
+      dgamma[col] = (accumulate ? dgamma[col] : 0.f) + b;
+      dbeta[col] = (accumulate ? dbeta[col] : 0.f) + a;
     }
   }
   __syncthreads();
   if (!live && !dbias) return;
   const float invR = 1.0f / (float)R;
   const float a = b1[tx] * invR, b = b2[tx] * invR;
-  const float sc = (live && gamma) ? rs * gamma[(long long)g * grp.gamma + col] : rs;
+  const float sc = (live && gamma) ? rs * gamma[col] : rs;
   float* bo = dx + (size_t)g * R * lddx + col;
   float sb = 0.f;
 #pragma unroll 8
@@ -462,8 +444,7 @@ __global__ __launch_bounds__(1024) void norm_small_bwd_k(const float* __restrict
   if (ty == 0 && live) {
     float t = 0.f;
     for (unsigned l = 0; l < 32; ++l) t += p1[l][tx];
-    float* dbi = dbias + (long long)g * grp.dbias;
-    dbi[col] = (accumulate_bias ? dbi[col] : 0.f) + t;
+    dbias[col] = (accumulate_bias ? dbias[col] : 0.f) + t;
   }
 }
 
@@ -502,16 +483,13 @@ long long so_norm_ws_floats(int G, long long R, int C) {
 // Training-mode statistics + normalisation.  mean/rstd: [G][C] outputs (saved for backward).
 static int norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* y2, int ldy2, int act2, float act2_param, int G,
                            long long R, int C, float eps, const float* gamma, const float* beta, float* mean, float* rstd,
-                           float* running_mean, float* running_var, float momentum, float* ws, void* stream,
-                           const NormGrp* grp_in = nullptr) {
+                           float* running_mean, float* running_var, float momentum, float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
-  if (running_mean && G != 1 && !grp_in) return SO_ERR_SHAPE;
-  const NormGrp grp = grp_in ? *grp_in : NormGrp{};
+  if (running_mean && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (R <= kSmallRows) {
     hipLaunchKernelGGL(norm_small_fwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, y, ldy, (unsigned)R,
-                       (unsigned)C, eps, gamma, beta, mean, rstd, running_mean, running_var, momentum, y2, ldy2, act2, act2_param,
-                       grp);
+                       (unsigned)C, eps, gamma, beta, mean, rstd, running_mean, running_var, momentum, y2, ldy2, act2, act2_param);
     return SO_LAUNCH_CHECK();
   }
   unsigned chunk, nchunk;
@@ -522,16 +500,16 @@ static int norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* y2
                      nchunk, ws);
   dim3 g2(so_cdiv(C, 16), G);
   hipLaunchKernelGGL(stats_final_k, g2, dim3(1024), 0, st, ws, nchunk, (unsigned)C, eps, mean, rstd,
-                     running_mean, running_var, momentum, grp);
+                     running_mean, running_var, momentum);
   if (!y) return SO_LAUNCH_CHECK();  // statistics only: the caller normalises inside its own pass (so_spade_norm_fwd)
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && al16(x) && al16(y) && al16(mean) && al16(rstd) &&
       (!y2 || ((ldy2 & 3) == 0 && al16(y2))))
     hipLaunchKernelGGL(norm_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param, grp);
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param);
   else
     hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, y, ldy,
-                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param, grp);
+                       (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, beta, 0, eps, y2, ldy2, act2, act2_param);
   return SO_LAUNCH_CHECK();
 }
 
@@ -560,22 +538,20 @@ int so_norm_apply(const float* x, int ldx, float* y, int ldy, int G, long long R
   const long long total = (long long)G * R * C;
   hipLaunchKernelGGL(norm_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                      y, ldy, (unsigned)G, (unsigned)R, (unsigned)C, mean, stat, gamma, beta,
-                     stat_is_var, eps, (float*)nullptr, 0, 0, 0.f, NormGrp{});
+                     stat_is_var, eps, (float*)nullptr, 0, 0, 0.f);
   return SO_LAUNCH_CHECK();
 }
 
 static int norm_bwd_launch(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int G,
                            long long R, int C, const float* mean, const float* rstd, const float* gamma,
                            float* dgamma, float* dbeta, int accumulate, int relu_gate, float* dbias, int accumulate_bias,
-                           float* ws, void* stream, const NormGrp* grp_in = nullptr) {
+                           float* ws, void* stream) {
   if (G <= 0 || R <= 0 || C <= 0) return 0;
-  if ((dgamma || dbias) && G != 1 && !grp_in) return SO_ERR_SHAPE;
-  const NormGrp grp = grp_in ? *grp_in : NormGrp{};
+  if ((dgamma || dbias) && G != 1) return SO_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (R <= kSmallRows) {
     hipLaunchKernelGGL(norm_small_bwd_k, dim3(so_cdiv(C, 32), G), dim3(1024), 0, st, x, ldx, dy, lddy, dx, lddx,
-                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, dbias, accumulate_bias,
-                       grp);
+                       (unsigned)R, (unsigned)C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, dbias, accumulate_bias);
     return SO_LAUNCH_CHECK();
   }
   unsigned chunk, nchunk;
@@ -590,26 +566,25 @@ static int norm_bwd_launch(const float* x, int ldx, const float* dy, int lddy, f
     hipLaunchKernelGGL(norm_bwd_partial_k<true>, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
                        (unsigned)C, chunk, nchunk, mean, rstd, part);
     hipLaunchKernelGGL(norm_bwd_final_k<true>, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
-                       dbeta, accumulate, rstd, gamma, invR, dbias, accumulate_bias, grp);
+                       dbeta, accumulate, rstd, gamma, invR, dbias, accumulate_bias);
   } else {
     hipLaunchKernelGGL(norm_bwd_partial_k<false>, g1, dim3(256), 0, st, x, ldx, dy, lddy, (unsigned)R,
                        (unsigned)C, chunk, nchunk, mean, rstd, part);
     hipLaunchKernelGGL(norm_bwd_final_k<false>, g2, dim3(1024), 0, st, part, nchunk, (unsigned)C, sums, dgamma,
-                       dbeta, accumulate, rstd, gamma, invR, (float*)nullptr, 0, grp);
+                       dbeta, accumulate, rstd, gamma, invR, (float*)nullptr, 0);
     if (dbias) {
       // ungated: the column sums of dx are -rstd gamma s2/R sum_r xhat = 0 up to round-off (sum_r xhat = 0): exact zero
-      if (!accumulate_bias)
-        for (int g = 0; g < (grp_in ? G : 1); ++g) (void)hipMemsetAsync(dbias + g * grp.dbias, 0, (size_t)C * sizeof(float), st);
+      if (!accumulate_bias) (void)hipMemsetAsync(dbias, 0, (size_t)C * sizeof(float), st);
     }
   }
   const long long total = (long long)G * R * C;
   if ((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && al16(x) && al16(dy) && al16(dx) && al16(mean) &&
       al16(rstd) && al16(sums))
     hipLaunchKernelGGL(norm_bwd_apply_k<4>, dim3(grid_for(total / 4)), dim3(256), 0, st, x, ldx, dy,
-                       lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate, grp);
+                       lddy, dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   else
     hipLaunchKernelGGL(norm_bwd_apply_k<1>, dim3(grid_for(total)), dim3(256), 0, st, x, ldx, dy, lddy,
-                       dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate, grp);
+                       dx, lddx, (unsigned)G, (unsigned)R, (unsigned)C, mean, rstd, gamma, sums, relu_gate);
   return SO_LAUNCH_CHECK();
 }
 
@@ -630,33 +605,6 @@ int so_norm_bwd_bias(const float* x, int ldx, const float* dy, int lddy, float* 
   if (!dbias) return SO_ERR_SHAPE;
   return norm_bwd_launch(x, ldx, dy, lddy, dx, lddx, G, R, C, mean, rstd, gamma, dgamma, dbeta, accumulate, relu_gate, dbias,
                          accumulate_bias, ws, stream);
-}
-
-// ---- pair launches: the BatchNorms of the GMM's two feature-extraction towers (warp.py:9-36) as ONE launch --------------
-// x / y / dy / dx hold tower 0's rows, then tower 1's (R rows each, G = 2 statistics domains); every per-channel tensor
-// (affine parameters, running statistics, their gradients, the producing convolutions' bias gradients) is two pointers.
-// mean / rstd: [2][C].  Same arithmetic per tower as so_norm_fwd / so_norm_bwd(_bias) with G = 1.
-int so_norm_fwd_pair(const float* x, int ldx, float* y, int ldy, long long R, int C, float eps, const float* gamma0,
-                     const float* beta0, const float* gamma1, const float* beta1, float* mean, float* rstd, float* rm0, float* rv0,
-                     float* rm1, float* rv1, float momentum, float* ws, void* stream) {
-  if (!gamma0 || !gamma1 || !beta0 || !beta1 || !rm0 || !rm1 || !rv0 || !rv1) return SO_ERR_SHAPE;
-  NormGrp grp = {};
-  grp.gamma = gamma1 - gamma0; grp.beta = beta1 - beta0; grp.rm = rm1 - rm0; grp.rv = rv1 - rv0;
-  return norm_fwd_launch(x, ldx, y, ldy, nullptr, 0, 0, 0.f, 2, R, C, eps, gamma0, beta0, mean, rstd, rm0, rv0, momentum, ws, stream,
-                         &grp);
-}
-
-int so_norm_bwd_pair(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, long long R, int C,
-                     const float* mean, const float* rstd, const float* gamma0, const float* gamma1, float* dgamma0, float* dbeta0,
-                     float* dgamma1, float* dbeta1, int accumulate, int relu_gate, float* dbias0, float* dbias1,
-                     int accumulate_bias, float* ws, void* stream) {
-  if (!gamma0 || !gamma1 || !dgamma0 || !dgamma1 || !dbeta0 || !dbeta1 || ((dbias0 == nullptr) != (dbias1 == nullptr)))
-    return SO_ERR_SHAPE;
-  NormGrp grp = {};
-  grp.gamma = gamma1 - gamma0; grp.dgamma = dgamma1 - dgamma0; grp.dbeta = dbeta1 - dbeta0;
-  grp.dbias = dbias0 ? dbias1 - dbias0 : 0;
-  return norm_bwd_launch(x, ldx, dy, lddy, dx, lddx, 2, R, C, mean, rstd, gamma0, dgamma0, dbeta0, accumulate, relu_gate, dbias0,
-                         accumulate_bias, ws, stream, &grp);
 }
 
 }  // extern "C"

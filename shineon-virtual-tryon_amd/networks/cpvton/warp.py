@@ -60,70 +60,6 @@ class FeatureExtraction(nn.Module):
         return x
 
 
-def _layer_groups(mods):
-    """[(conv, has_relu, bn or None)] of a FeatureExtraction's nn.Sequential, or None if it is not a chain of such groups."""
-    out, i = [], 0
-    while i < len(mods):
-        m = mods[i]
-        if not isinstance(m, HipConv2d) or m.fuse_relu:
-            return None
-        relu = i + 1 < len(mods) and isinstance(mods[i + 1], HipReLU)
-        j = i + 1 + int(relu)
-        bn = mods[j] if j < len(mods) and isinstance(mods[j], HipBatchNorm2d) else None
-        out.append((m, relu, bn))
-        i = j + int(bn is not None)
-    return out
-
-
-def twin_feature_extraction(ext_a, ext_b, x_a, x_b):
-    """ext_a(x_a), ext_b(x_b) for the GMM's two towers (models/warp_model.py:45-53, 66-67) with every layer from the second on
-    as ONE launch per kernel on a [2B] batch: the towers have identical layer shapes (only the first convolution's input
-    channels differ) and different weights, and at 16x12 .. 64x48 feature maps each tower alone fills a fraction of the chip.
-    Same arithmetic per tower as FeatureExtraction.forward (ops.conv2d_pair / batch_norm_train_pair call the single-tower
-    kernels' grouped forms).  Returns None when the pair path does not apply (eval mode, no gradients, parameters outside the
-    optimizer's slab, different tower structures): the caller runs the towers one by one."""
-    if not (ext_a.training and ext_b.training and torch.is_grad_enabled() and x_a.is_cuda and x_a.shape[0] == x_b.shape[0]):
-        return None
-    ga, gb = _layer_groups(list(ext_a.model)), _layer_groups(list(ext_b.model))
-    if ga is None or gb is None or len(ga) != len(gb) or len(ga) < 2:
-        return None
-    for k, ((ca, ra, ba), (cb, rb, bb)) in enumerate(zip(ga, gb)):
-        same = (ca.weight.shape[0] == cb.weight.shape[0] and ca.weight.shape[2:] == cb.weight.shape[2:] and ca.stride == cb.stride
-                and ca.padding == cb.padding and ra and rb and (ba is None) == (bb is None)
-                and (k == 0 or ca.weight.shape[1] == cb.weight.shape[1]) and ca.weight.shape[0] % 4 == 0)
-        if not same or not ops.pair_ok(ca.weight, ca.bias, cb.weight, cb.bias):
-            return None
-        if ba is not None and not (ops.pair_ok(ba.weight, ba.bias, bb.weight, bb.bias) and ba.momentum == bb.momentum
-                                   and ba.eps == bb.eps):
-            return None
-    nb = x_a.shape[0]
-
-    def bn_args(bn):
-        if bn.count_batches and not bn._shared_counter:
-            bn.num_batches_tracked += 1
-        return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-
-    # first layer: different input channels - two launches writing the two halves of one buffer
-    (ca, _, ba), (cb, _, bb) = ga[0], gb[0]
-    o = ca.weight.shape[0]
-    r, st, pd = ca.weight.shape[2], ca.stride, ca.padding
-    ho, wo = (x_a.shape[2] + 2 * pd - r) // st + 1, (x_a.shape[3] + 2 * pd - r) // st + 1
-    buf = ops.nhwc_empty(2 * nb, ho, wo, o, x_a.device)
-    gate = ba is not None
-    ya = ops.conv2d(x_a, ca.weight, ca.bias, st, pd, ops.ACT_RELU, act_grad_external=gate, bias_grad_external=gate, out=buf[:nb])
-    yb = ops.conv2d(x_b, cb.weight, cb.bias, st, pd, ops.ACT_RELU, act_grad_external=gate, bias_grad_external=gate, out=buf[nb:])
-    x2 = ops.join_halves(ya, yb, buf)
-    if ba is not None:
-        x2 = ops.batch_norm_train_pair(x2, bn_args(ba), bn_args(bb), relu_gate_input=True, conv_bias=(ca.bias, cb.bias))
-    for (ca, _, ba), (cb, _, bb) in zip(ga[1:], gb[1:]):
-        gate = ba is not None
-        x2 = ops.conv2d_pair(x2, ca.weight, ca.bias, cb.weight, cb.bias, ca.stride, ca.padding, ops.ACT_RELU,
-                             act_grad_external=gate, bias_grad_external=gate)
-        if ba is not None:
-            x2 = ops.batch_norm_train_pair(x2, bn_args(ba), bn_args(bb), relu_gate_input=True, conv_bias=(ca.bias, cb.bias))
-    return x2[:nb], x2[nb:]
-
-
 class FeatureL2Norm(nn.Module):
     def forward(self, feature, transpose_hw=False):
         return ops.feature_l2norm(feature, transpose_hw)

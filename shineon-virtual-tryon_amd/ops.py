@@ -316,7 +316,7 @@ class _Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, zero_bias_grad, act_grad_external=False, act_param=0.0,
-                bias_grad_hint=False, forward_only=False, bias_grad_external=False, out=None):
+                bias_grad_hint=False, forward_only=False, bias_grad_external=False):
         L = lib()
         ctx.bias_hint = bool(bias_grad_hint)
         ctx.bias_external = bool(bias_grad_external)
@@ -337,13 +337,7 @@ class _Conv2dFn(torch.autograd.Function):
         n, _, h, wd = xr.shape
         ho = (h + 2 * pad - r) // stride + 1
         wo = (wd + 2 * pad - s) // stride + 1
-        if out is not None:
-            # the caller's buffer (one half of a twin-tower activation, ops.join_halves): dense rows of exactly op channels
-            if tuple(out.shape) != (n, op, ho, wo) or not _is_rows(out) or _ld(out) != op or out.data_ptr() % 16:
-                raise ValueError("conv2d(out=...): expected a dense NHWC-rows buffer of the output's shape")
-            y = out
-        else:
-            y = nhwc_empty(n, ho, wo, op, x.device)
+        y = nhwc_empty(n, ho, wo, op, x.device)
         ws = workspace(x.device)
         wino = _wino_mode(cp, op, n, h, wd) if (r == 3 and s == 3 and stride == 1 and pad == 1 and
                                                   n * h * wd >= WINOGRAD_TRAINABLE_MIN_PIXELS) else "direct"
@@ -476,11 +470,11 @@ class _Conv2dFn(torch.autograd.Function):
         if need_w or need_b:
             dw, db = weight_grads(lane=0)
         grad_ready(w_direct, b_direct)   # both the input- and the weight-gradient kernels of this layer are in the stream
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_grad=False, act_grad_external=False,
-           act_param=0.0, bias_grad_hint=False, bias_grad_external=False, out=None):
+           act_param=0.0, bias_grad_hint=False, bias_grad_external=False):
     """nn.Conv2d forward (+ optional fused ReLU epilogue) on fp32 MFMA.  zero_bias_grad: the caller guarantees the
     output feeds an Instance/BatchNorm directly, so d loss / d bias is exactly zero and is not computed.
     act_grad_external: the only consumer of the output multiplies the gradient by the activation's mask itself
@@ -490,171 +484,13 @@ def conv2d(x, weight, bias=None, stride=1, padding=1, act=ACT_NONE, zero_bias_gr
     if bias_grad_external and not (bias is not None and _direct_grad_ok(bias, False)):
         raise RuntimeError("conv2d(bias_grad_external=True) needs a bias whose gradient lives in the optimizer's slab")
     return _Conv2dFn.apply(x, weight, bias, stride, padding, act, zero_bias_grad, act_grad_external, act_param, bias_grad_hint,
-                           _forward_only(x, weight, bias), bias_grad_external, out)
+                           _forward_only(x, weight, bias), bias_grad_external)
 
 
 def _forward_only(*ts):
     """True when no gradient can be asked of this call (grad mode off, or nothing requires grad).  Inside an
     autograd.Function's forward grad mode is always off and needs_input_grad follows requires_grad, so the wrappers decide."""
     return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
-
-
-# ------------------------------------------------------------------------------------------------
-# twin towers: the GMM's two feature extractions (models/networks/cpvton/warp.py:9-36, built twice at warp_model.py:45-53) run
-# identical layer shapes on different inputs with different weights - from the second layer on every convolution, BatchNorm
-# and gradient kernel of the two towers is ONE launch on a [2B] batch (tower A's images, then tower B's).
-# ------------------------------------------------------------------------------------------------
-class _JoinHalvesFn(torch.autograd.Function):
-    """(2B, C, H, W) buffer whose two batch halves were written in place by two producers (conv2d(out=...)); the gradient of
-    each half goes back to its producer (views, no copy)."""
-
-    @staticmethod
-    def forward(ctx, a, b, buf):
-        ctx.nb = a.shape[0]
-        return buf.view_as(buf)
-
-    @staticmethod
-    def backward(ctx, g):
-        g = to_rows(g)
-        return g[:ctx.nb], g[ctx.nb:], None
-
-
-def join_halves(a, b, buf):
-    if a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf[a.shape[0]:].data_ptr():
-        raise ValueError("join_halves: the halves are not views of the buffer")
-    return _JoinHalvesFn.apply(a, b, buf)
-
-
-class _Conv2dPairFn(torch.autograd.Function):
-    """conv2d of tower A's images with (wA, bA) and of tower B's with (wB, bB) - same shapes - as one launch each for the
-    forward pass, the input gradients and the weight gradients (so_conv2d_*_pair).  All four parameters live in the
-    optimizer's slab (gradients accumulated in place)."""
-
-    @staticmethod
-    def forward(ctx, x2, wa, ba, wb, bb, stride, pad, act, act_grad_external, bias_grad_external):
-        L = lib()
-        if act not in (ACT_NONE, ACT_RELU, ACT_LEAKY):
-            raise ValueError("conv2d_pair fuses ReLU / LeakyReLU only")
-        x2 = _dense_rows(x2)
-        n2, c, h, w = x2.shape
-        o, i, r, s = wa.shape
-        if tuple(wb.shape) != (o, i, r, s) or i != c or (c % 4) or (o % 4) or n2 % 2:
-            raise ValueError("conv2d_pair: the two towers must share the layer shape (channels multiples of 4)")
-        va, vb = _ohwi(wa), _ohwi(wb)                       # views: slab-planted parameters are OHWI in memory
-        if va.data_ptr() != wa.data_ptr() or vb.data_ptr() != wb.data_ptr():
-            raise ValueError("conv2d_pair needs OHWI parameters in place (optimizer slab)")
-        nb = n2 // 2
-        ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
-        y2 = nhwc_empty(n2, ho, wo, o, x2.device)
-        ws = workspace(x2.device)
-        check(L.so_conv2d_fprop_pair(x2.data_ptr(), _ld(x2), va.data_ptr(), vb.data_ptr(), ba.data_ptr(), bb.data_ptr(),
-                                     y2.data_ptr(), o, nb, h, w, c, o, r, s, stride, pad, act, 0.0, ws.data_ptr(), ws.numel() * 4,
-                                     _stream()), "conv2d_fprop_pair")
-        ctx.save_for_backward(x2, va, vb, y2 if act != ACT_NONE and not act_grad_external else None)
-        ctx.cfg = (stride, pad, ACT_NONE if act_grad_external else act, bool(bias_grad_external))
-        ctx.params = (wa, ba, wb, bb)
-        return y2
-
-    @staticmethod
-    def backward(ctx, dy2):
-        L = lib()
-        x2, va, vb, y2 = ctx.saved_tensors
-        stride, pad, act, bias_external = ctx.cfg
-        wa, ba, wb, bb = ctx.params
-        n2, c, h, w = x2.shape
-        o, r, s, _ = va.shape
-        nb = n2 // 2
-        dy2 = _dense_rows(dy2)
-        dev = dy2.device
-        rows = dy2.shape[0] * dy2.shape[2] * dy2.shape[3]
-        if act != ACT_NONE:
-            g = nhwc_empty(dy2.shape[0], dy2.shape[2], dy2.shape[3], o, dev)
-            check(L.so_act_bwd(y2.data_ptr(), o, dy2.data_ptr(), _ld(dy2), g.data_ptr(), o, rows, o, act, 0.0, _stream()), "act_bwd")
-            dy2 = g
-        ws = workspace(dev)
-        dx2 = None
-        if ctx.needs_input_grad[0]:
-            dx2 = nhwc_empty(n2, h, w, c, dev)
-            check(L.so_conv2d_dgrad_pair(dy2.data_ptr(), _ld(dy2), va.data_ptr(), vb.data_ptr(), dx2.data_ptr(), c, nb, h, w, c, o,
-                                         r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()), "conv2d_dgrad_pair")
-        check(L.so_conv2d_wgrad_acc_pair(dy2.data_ptr(), _ld(dy2), x2.data_ptr(), _ld(x2), wa.grad.data_ptr(), wb.grad.data_ptr(),
-                                         nb, h, w, c, o, r, s, stride, pad, ws.data_ptr(), ws.numel() * 4, _stream()),
-              "conv2d_wgrad_acc_pair")
-        if not bias_external:
-            half = rows // 2
-            for k, bpar in enumerate((ba, bb)):
-                wsb = workspace(dev, L.so_colsum_ws_floats(half, o) * 4, lane=2)
-                check(L.so_colsum(dy2.data_ptr() + 4 * k * half * _ld(dy2), _ld(dy2), half, o, bpar.grad.data_ptr(), 1,
-                                  wsb.data_ptr(), _stream()), "colsum")
-        grad_ready(wa, ba, wb, bb)
-        return dx2, None, None, None, None, None, None, None, None, None
-
-
-def conv2d_pair(x2, wa, ba, wb, bb, stride=1, padding=1, act=ACT_NONE, act_grad_external=False, bias_grad_external=False):
-    """x2: (2B, C, H, W), tower A's batch then tower B's.  Needs both towers' parameters in the optimizer's slab."""
-    if not all(_direct_grad_ok(t, ohwi=t.dim() == 4) for t in (wa, ba, wb, bb)):
-        raise RuntimeError("conv2d_pair needs parameters whose gradients live in the optimizer's slab (optim.HipAdam)")
-    return _Conv2dPairFn.apply(x2, wa, ba, wb, bb, stride, padding, act, act_grad_external, bias_grad_external)
-
-
-def pair_ok(*params):
-    """True when the parameters can take the pair kernels: gradients planted in the optimizer's slab, OHWI in place."""
-    return all(p is not None and p.requires_grad and _direct_grad_ok(p, ohwi=p.dim() == 4) for p in params)
-
-
-class _NormPairFn(torch.autograd.Function):
-    """BatchNorm2d (training) of tower A's half of x2 with bnA's parameters and of tower B's half with bnB's, as ONE launch per
-    kernel (so_norm_fwd_pair / so_norm_bwd_pair: G = 2 statistics domains, every per-channel tensor two pointers).
-    relu_gate / conv biases as in batch_norm_train."""
-
-    @staticmethod
-    def forward(ctx, x2, ga, bta, rma, rva, gb, btb, rmb, rvb, momentum, eps, relu_gate, cba, cbb):
-        L = lib()
-        x2 = to_rows(x2)
-        n2, c, h, w = x2.shape
-        R = (n2 // 2) * h * w
-        y2 = nhwc_empty(n2, h, w, c, x2.device)
-        mean = torch.empty((2, c), dtype=torch.float32, device=x2.device)
-        rstd = torch.empty((2, c), dtype=torch.float32, device=x2.device)
-        ws = workspace(x2.device, L.so_norm_ws_floats(2, R, c) * 4)
-        check(L.so_norm_fwd_pair(x2.data_ptr(), _ld(x2), y2.data_ptr(), c, R, c, eps, ga.data_ptr(), bta.data_ptr(), gb.data_ptr(),
-                                 btb.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rma.data_ptr(), rva.data_ptr(), rmb.data_ptr(),
-                                 rvb.data_ptr(), momentum, ws.data_ptr(), _stream()), "norm_fwd_pair")
-        ctx.save_for_backward(x2, mean, rstd)
-        ctx.params = (ga, bta, gb, btb, cba, cbb)
-        ctx.cfg = (R, bool(relu_gate))
-        return y2
-
-    @staticmethod
-    def backward(ctx, dy2):
-        L = lib()
-        x2, mean, rstd = ctx.saved_tensors
-        ga, bta, gb, btb, cba, cbb = ctx.params
-        R, relu_gate = ctx.cfg
-        n2, c, h, w = x2.shape
-        dy2 = to_rows(dy2)
-        dx2 = nhwc_empty(n2, h, w, c, x2.device)
-        ws = workspace(x2.device, L.so_norm_ws_floats(2, R, c) * 4)
-        check(L.so_norm_bwd_pair(x2.data_ptr(), _ld(x2), dy2.data_ptr(), _ld(dy2), dx2.data_ptr(), c, R, c, mean.data_ptr(),
-                                 rstd.data_ptr(), ga.data_ptr(), gb.data_ptr(), ga.grad.data_ptr(), bta.grad.data_ptr(),
-                                 gb.grad.data_ptr(), btb.grad.data_ptr(), 1, int(relu_gate),
-                                 cba.grad.data_ptr() if cba is not None else None, cbb.grad.data_ptr() if cbb is not None else None,
-                                 1, ws.data_ptr(), _stream()), "norm_bwd_pair")
-        grad_ready(ga, bta, gb, btb)
-        return (dx2,) + (None,) * 13
-
-
-def batch_norm_train_pair(x2, bn_a, bn_b, relu_gate_input=False, conv_bias=None):
-    """bn_a / bn_b: (gamma, beta, running_mean, running_var, momentum, eps) of the two towers' layers; conv_bias: the two
-    producing convolutions' biases (their gradients come out of this node's backward pass) or None."""
-    ga, bta, rma, rva, mom, eps = bn_a
-    gb, btb, rmb, rvb, mom_b, eps_b = bn_b
-    if mom != mom_b or eps != eps_b or not pair_ok(ga, bta, gb, btb):
-        raise RuntimeError("batch_norm_train_pair: the two layers must share momentum / eps and live in the optimizer's slab")
-    cba, cbb = conv_bias if conv_bias is not None else (None, None)
-    if cba is not None and not (relu_gate_input and pair_ok(cba, cbb)):
-        raise RuntimeError("batch_norm_train_pair(conv_bias=...) needs relu_gate_input and slab-planted biases")
-    return _NormPairFn.apply(x2, ga, bta, rma, rva, gb, btb, rmb, rvb, float(mom), float(eps), relu_gate_input, cba, cbb)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -14,15 +14,13 @@ from .base_model import BaseModel
 from .io_png import StageWriter
 from .networks.layers import HipBatchNorm2d, share_bn_counters
 from .networks.cpvton.warp import (FeatureCorrelation, FeatureExtraction, FeatureL2Norm, FeatureRegression,
-                                   TpsGridGen, twin_feature_extraction)
+                                   TpsGridGen)
 from .pl_compat import EvalResult, TrainResult
 from .util import get_and_cat_inputs, maybe_combine_frames_and_channels
 
 
 # the two towers on two streams (see WarpModel.forward); SHINEON_TOWER_STREAMS=0 runs them one after the other
 TOWER_STREAMS = os.environ.get("SHINEON_TOWER_STREAMS", "1") != "0"
-# both towers' layers as one launch per kernel (networks/cpvton/warp.py:twin_feature_extraction); 0: one tower after / beside the other
-TWIN_TOWERS = os.environ.get("SHINEON_TWIN_TOWERS", "1") != "0"
 
 
 class WarpModel(BaseModel):
@@ -50,7 +48,6 @@ class WarpModel(BaseModel):
         # the chained warp -> try-on schedule (whose warp stage already shares the chip with the try-on stage on a second
         # stream) 612 -> 521, so trainer.ChainedTrainStep switches it off for its warp model.
         self.tower_streams = TOWER_STREAMS
-        self.twin_towers = TWIN_TOWERS
 
     def batch_keys(self):
         """Tensor entries of the batch dict this model reads (training / validation / test)."""
@@ -77,12 +74,7 @@ class WarpModel(BaseModel):
     def forward(self, inputA, inputB):
         if self.training:
             self._bump_bn_counters()
-        twin = twin_feature_extraction(self.extractionA, self.extractionB, inputA, inputB) if (self.twin_towers and inputA.is_cuda) else None
-        if twin is not None:
-            # both towers' layers as ONE launch per kernel (round 6): see networks/cpvton/warp.py:twin_feature_extraction
-            featureA = self.l2norm(twin[0], transpose_hw=True)
-            featureB = self.l2norm(twin[1])
-        elif self.tower_streams and inputA.is_cuda:
+        if self.tower_streams and inputA.is_cuda:
             # The two feature-extraction towers (warp.py:9-36) are independent until the correlation and, at 16x12 .. 128x96
             # feature maps, every one of their kernels fills a fraction of the 256 CUs: the cloth tower runs on a forked stream
             # with its own scratch lane (eagerly and as a parallel branch of a captured graph); autograd replays the same

@@ -326,66 +326,6 @@ def test_conv_bias_gradient_from_the_batchnorm_backward(ops, cuda, hw):
         assert_close(got[True][k], got[False][k], atol=1e-4 if k == "b" else 0.0, what=f"d{k}: BatchNorm-side vs column sums {hw}")
 
 
-@pytest.mark.parametrize("hw,k,stride,pad,splitk", [((16, 12), 3, 1, 1, 1), ((16, 12), 3, 1, 1, 4), ((32, 24), 4, 2, 1, 2)])
-def test_twin_tower_pair_launches_are_bit_identical_to_separate_launches(ops, cuda, hw, k, stride, pad, splitk):
-    """ops.conv2d_pair / batch_norm_train_pair (the GMM's two feature-extraction towers as ONE launch per kernel, warp.py:9-36):
-    with the tile and split-K factor pinned, every output and gradient of the pair path equals - bit for bit - what the two
-    single-tower paths give on the same halves (the grouped kernels run the single-tower arithmetic per group)."""
-    from shineon_virtual_tryon_amd.optim import HipAdam
-
-    L = ops.lib()
-    nb, c, o = 2, 32, 64
-    xa, xb = rnd(nb, c, hw[0], hw[1], seed=60), rnd(nb, c, hw[0], hw[1], seed=61)
-    vals = {}
-    for t, sd in (("a", 62), ("b", 70)):
-        vals[t] = dict(w=rnd(o, c, k, k, seed=sd, scale=0.1), b=rnd(o, seed=sd + 1, scale=0.1), g=rnd(o, seed=sd + 2) * 0.1 + 1,
-                       be=rnd(o, seed=sd + 3) * 0.1)
-    ho, wo = (hw[0] + 2 * pad - k) // stride + 1, (hw[1] + 2 * pad - k) // stride + 1
-    seed_out = rnd(2 * nb, o, ho, wo, seed=80).to(cuda)
-
-    def build():
-        prm = {t: {n: torch.nn.Parameter(v.clone().to(cuda)) for n, v in vals[t].items()} for t in "ab"}
-        opt = HipAdam([q for t in "ab" for q in prm[t].values()], lr=1e-3)
-        opt.zero_grad()
-        run = {t: (torch.zeros(o, device=cuda), torch.ones(o, device=cuda)) for t in "ab"}
-        return prm, run
-
-    L.so_igemm_force(64, 64, splitk)
-    try:
-        # separate
-        prm, run = build()
-        xs = {t: x.clone().to(cuda).requires_grad_(True) for t, x in (("a", xa), ("b", xb))}
-        outs = []
-        for t in "ab":
-            y = ops.conv2d(xs[t], prm[t]["w"], prm[t]["b"], stride, pad, ops.ACT_RELU, act_grad_external=True, bias_grad_external=True)
-            outs.append(ops.batch_norm_train(y, prm[t]["g"], prm[t]["be"], run[t][0], run[t][1], 0.1, 1e-5, relu_gate_input=True,
-                                             conv_bias=prm[t]["b"]))
-        (ops.cat_batch(outs) * seed_out).sum().backward()
-        want = dict(out=[t_.detach().clone() for t_ in outs], dx=[xs[t].grad.clone() for t in "ab"],
-                    g={t: {n: q.grad.clone() for n, q in prm[t].items()} for t in "ab"}, run={t: [r.clone() for r in run[t]] for t in "ab"})
-        # pair
-        prm, run = build()
-        x2 = torch.cat([xa, xb]).to(cuda).requires_grad_(True)
-        y2 = ops.conv2d_pair(x2, prm["a"]["w"], prm["a"]["b"], prm["b"]["w"], prm["b"]["b"], stride, pad, ops.ACT_RELU,
-                             act_grad_external=True, bias_grad_external=True)
-        o2 = ops.batch_norm_train_pair(y2, (prm["a"]["g"], prm["a"]["be"], run["a"][0], run["a"][1], 0.1, 1e-5),
-                                       (prm["b"]["g"], prm["b"]["be"], run["b"][0], run["b"][1], 0.1, 1e-5), relu_gate_input=True,
-                                       conv_bias=(prm["a"]["b"], prm["b"]["b"]))
-        (o2 * seed_out).sum().backward()
-    finally:
-        L.so_igemm_force(0, 0, 0)
-    for i, t in enumerate("ab"):
-        assert torch.equal(o2[i * nb:(i + 1) * nb], want["out"][i]), f"forward, tower {t}"
-        assert torch.equal(x2.grad[i * nb:(i + 1) * nb], want["dx"][i]), f"input gradient, tower {t}"
-        for n in ("w", "b", "g", "be"):
-            assert torch.equal(prm[t][n].grad, want["g"][t][n]), f"d{n}, tower {t}"
-        assert torch.equal(run[t][0], want["run"][t][0]) and torch.equal(run[t][1], want["run"][t][1]), f"running statistics, tower {t}"
-    # and against torch
-    ref = F.batch_norm(F.relu(F.conv2d(xa, vals["a"]["w"], vals["a"]["b"], stride=stride, padding=pad)), torch.zeros(o), torch.ones(o),
-                       vals["a"]["g"], vals["a"]["be"], True, 0.1, 1e-5)
-    assert_close(o2[:nb], ref, atol=2e-5, what="pair path vs torch, tower a")
-
-
 @pytest.mark.parametrize("kind,ref", [("relu", F.relu), ("gelu", F.gelu), ("leaky", lambda t: F.leaky_relu(t, 0.2))])
 @pytest.mark.parametrize("c", [8, 6])
 def test_activation_fused_into_upsample(ops, cuda, kind, ref, c):
