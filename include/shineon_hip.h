@@ -122,6 +122,9 @@ int so_wino_fused_conv3x3_pool(const float* x, int ldx, const float* U, const fl
 /* -1 (default) = 64 output channels per block (two blocks per CU) when Ko >= 64 and that grid still has >= 1024 blocks, else 32
  * (three per CU); 1 = always 32; 0 = 64 whenever Ko >= 64 */
 void so_wino_fused_force_kb32(int on);
+/* block order of the fused kernel: -1 (default) = the ko blocks of a patch adjacent unless the Winograd-domain filters exceed
+ * 8 MB, then all patches of a ko block adjacent (its filter slice stays in the XCD's L2); 0 / 1 force either (A/B measurements) */
+void so_wino_fused_kb_major(int mode);
 /* csrc/attn.hip: SAGAN self-attention core for n = H*W <= 256 positions (sagan.py:38-52) on qkv = [q | k | v] rows ([B n][E], the
  * output of ONE projection GEMM).  so_attn_supported: 1 when the fused kernels take the shape (C % 32 == 0, d % 4 == 0, LDS fits);
  * so_attn_fwd: energy -> softmax -> attention x V -> gamma * o + x in one launch (a: [B][n][n], o: [B n][C], both may be NULL);

@@ -204,6 +204,7 @@ struct WinoP {
   int ldx, ldy, Nb, H, W, C, Ko, nbias, pbx, pby, nkb, nks, act;
   int ldyp, n_keep;    // images >= n_keep do not store y at all (their un-pooled activations are never read)
   float act_param;
+  int kb_major, npatch;   // block order: 0 = (patch, ko block) with the ko block fastest, 1 = (ko block, patch) with the patch fastest
 };
 
 #define WF_SB() __builtin_amdgcn_sched_barrier(0x006)
@@ -258,8 +259,13 @@ __global__ __launch_bounds__(WF_NT, NKG == 1 ? 3 : 2) void wino_fused_k(const Wi
   const unsigned tot = gridDim.x, lin = blockIdx.x;
   const unsigned xper = tot >> 3, xrem = tot & 7, xcd = lin & 7;
   const unsigned lg = xcd * xper + (xcd < xrem ? xcd : xrem) + (lin >> 3);
-  const int kb = (int)(lg % (unsigned)p.nkb);
-  const int patch = (int)(lg / (unsigned)p.nkb);
+  // Two orders of the (patch, ko block) items along that list.  ko block fastest (VGG: large activations, <= 1 MB of
+  // Winograd-domain filters): the ko blocks of one patch re-read the same input pixels out of L2.  Patch fastest (round 6; the
+  // 512-1024-channel layers of the SAMS generator: 17-67 MB of filters, small maps): an XCD then works through ONE ko block's
+  // filter slice (<= 4 MB, L2-resident) for all patches instead of streaming the whole filter tensor once per patch -
+  // measured on SAMS' most frequent layers as 2 x the kernel's algorithmic bytes (profiles/r05 traffic_ratio 1.82).
+  const int kb = p.kb_major ? (int)(lg / (unsigned)p.npatch) : (int)(lg % (unsigned)p.nkb);
+  const int patch = p.kb_major ? (int)(lg % (unsigned)p.npatch) : (int)(lg / (unsigned)p.nkb);
   const int pxb = patch % p.pbx;
   const int t2 = patch / p.pbx;
   const int pyb = t2 % p.pby;
@@ -965,6 +971,8 @@ int so_wino_fused_weights(const float* w, float* U, int Ko, int Kw, int C, int f
 // so_wino_fused_force_kb32: 1 = always 32, 0 = 64 whenever Ko >= 64, -1 (default) = that rule.
 static int g_wino_force_nkg1 = -1;
 void so_wino_fused_force_kb32(int on) { g_wino_force_nkg1 = on; }
+static int g_wino_kb_major = -1;   // -1: by filter size (default); 0 / 1: forced (A/B measurements, tools/one_layer.py)
+void so_wino_fused_kb_major(int mode) { g_wino_kb_major = mode; }
 static int g_wino_dma = 1;
 void so_wino_fused_dma(int on) { g_wino_dma = on; }   // 1 (default): LDS-DMA staging; 0: the register-staged form (A/B measurements)
 // (A barrier-free variant - every wave staging only its own operands: B fragments straight from L2 into registers, its 8 of
@@ -1016,6 +1024,11 @@ static int wino_fused_launch(const float* x, int ldx, const float* U, const floa
   const int KB = 32 * nkg;
   p.nkb = (Ko + KB - 1) / KB; p.nks = (C + 7) / 8;
   p.act = act; p.act_param = act_param;
+  p.npatch = Nb * p.pbx * p.pby;
+  // filters far beyond an XCD's 4 MB L2 (>= 512 x 512 channels): walk the patches inside a ko block (see the kernel).  Measured,
+  // warm clocks, 4 images: 1024 -> 1024 at 32x24 372 -> 354 us, at 16x12 118 -> 110, 512 -> 512 at 64x48 282 -> 278; at 4 MB
+  // (256 -> 256 at 128x96) the other order wins, 264 vs 269
+  p.kb_major = (g_wino_kb_major < 0 ? (ub > (8ll << 20) && p.nkb >= 2) : g_wino_kb_major) ? 1 : 0;
   const long long blocks = (long long)Nb * p.pbx * p.pby * p.nkb;
   if (blocks <= 0 || blocks > 0x7FFFFFFF) return SO_ERR_SHAPE;
   const bool dma = g_wino_dma != 0;

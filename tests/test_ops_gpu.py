@@ -457,6 +457,34 @@ def test_forward_only_weight_caches_follow_the_parameters(ops, cuda):
     assert torch.equal(ops.to_nchw(yc), y2)
 
 
+def test_winograd_fused_block_orders_are_bit_identical(ops, cuda):
+    """so_wino_fused_kb_major: the two block orders of the fused kernel (ko block fastest / patch fastest, chosen by filter
+    size) only change which L2 an item's operands are fetched into - the results must be the same bits."""
+    L = ops.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nb, h, w, c, ko = 2, 24, 20, 64, 160      # ragged patches, three 64-channel ko blocks (the last one partial)
+    x = rnd(nb, h, w, c, seed=98).to(cuda)
+    wt = (rnd(ko, 3, 3, c, seed=99) * 0.05).to(cuda)
+    u = torch.empty(L.so_wino_fused_weight_floats(ko, c, 0), device=cuda)
+    assert L.so_wino_fused_weights(wt.data_ptr(), u.data_ptr(), ko, ko, c, 0, st) == 0
+    outs = []
+    try:
+        for mode in (0, 1):
+            L.so_wino_fused_kb_major(mode)
+            for kb32 in (1, 0):
+                L.so_wino_fused_force_kb32(kb32)
+                y = torch.full((nb, h, w, ko), float("nan"), device=cuda)
+                assert L.so_wino_fused_conv3x3(x.data_ptr(), c, u.data_ptr(), None, 0, None, y.data_ptr(), ko, nb, h, w, c, ko, 1, 0.0, st) == 0
+                outs.append(y)
+    finally:
+        L.so_wino_fused_kb_major(-1)
+        L.so_wino_fused_force_kb32(-1)
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0]).any()
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])
+
+
 @pytest.mark.parametrize("n_keep", [0, 2, 4])
 def test_winograd_fused_conv_with_pooling_epilogue(ops, cuda, n_keep):
     """so_wino_fused_conv3x3_pool (VGG conv1_2 / conv2_2, vgg.py:14-25): conv + bias + ReLU with MaxPool2d(2, 2) written by the

@@ -21,6 +21,8 @@ def main():
     L = pkg.lib()
     if os.environ.get("WINO_DMA") is not None:      # fused Winograd kernel: LDS-DMA staging (1, default) or registers (0)
         L.so_wino_fused_dma(int(os.environ["WINO_DMA"]))
+    if os.environ.get("WINO_KBMAJOR") is not None:  # fused Winograd block order: 0 ko block fastest, 1 patch fastest, -1 rule
+        L.so_wino_fused_kb_major(int(os.environ["WINO_KBMAJOR"]))
     if os.environ.get("WINO_KB32") is not None:     # 1 (default): 32 output channels per block; 0: 64 where Ko >= 64
         L.so_wino_fused_force_kb32(int(os.environ["WINO_KB32"]))
     dev = torch.device("cuda", 0)
