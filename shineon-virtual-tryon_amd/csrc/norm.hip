@@ -90,12 +90,23 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
   const unsigned tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const unsigned c = blockIdx.x * 16u + tx;
   const unsigned g = blockIdx.y;
+  // The partials were written by other XCDs a moment ago (L2 misses): all of a thread's <= FB loads go out as ONE batch, the
+  // merges then run in the same order as before (a batch of four at a time was four dependent memory latencies per launch).
   Mom acc = {0.f, 0.f, 0.f};
   if (c < C) {
-#pragma unroll 4
-    for (unsigned k = ty; k < nchunk; k += 64) {
-      const float* o = part + ((size_t)g * nchunk + k) * 3 * C;
-      acc = mom_merge(acc, Mom{o[c], o[C + c], o[2 * C + c]});
+    constexpr int FB = 16;   // chunking() keeps nchunk <= 1024 = 64 lanes x 16: one batch
+    for (unsigned k0 = ty; k0 < nchunk; k0 += 64u * FB) {
+      float pn[FB], pm[FB], p2[FB];
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        const unsigned k = k0 + 64u * j;
+        const float* o = part + ((size_t)g * nchunk + (k < nchunk ? k : 0u)) * 3 * C;
+        pn[j] = k < nchunk ? o[c] : 0.f;
+        pm[j] = o[C + c];
+        p2[j] = o[2 * C + c];
+      }
+#pragma unroll
+      for (int j = 0; j < FB; ++j) acc = mom_merge(acc, Mom{pn[j], pm[j], p2[j]});   // n == 0: identity
     }
   }
   sn[threadIdx.x] = acc.n; sm[threadIdx.x] = acc.mean; s2[threadIdx.x] = acc.m2;
@@ -237,24 +248,40 @@ __global__ __launch_bounds__(1024) void norm_bwd_final_k(const float* __restrict
   float a[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) a[k] = 0.f;
-  if (c < C) {
-#pragma unroll 4
-    for (unsigned k = ty; k < nchunk; k += 64) {
-      const float* o = part + ((size_t)g * nchunk + k) * NS * C;
+  if (c < C) {   // batched loads, then the adds in the old order (see stats_final_k); 80 values at once would spill
+    constexpr int FB = GATED ? 8 : 16;
+    for (unsigned k0 = ty; k0 < nchunk; k0 += 64u * FB) {
+      float v[FB][NS];
 #pragma unroll
-      for (int q = 0; q < NS; ++q) a[q] += o[q * C + c];
+      for (int j = 0; j < FB; ++j) {
+        const unsigned k = k0 + 64u * j;
+        const float* o = part + ((size_t)g * nchunk + (k < nchunk ? k : 0u)) * NS * C;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) v[j][q] = o[q * C + c];
+      }
+#pragma unroll
+      for (int j = 0; j < FB; ++j) {
+        if (k0 + 64u * j < nchunk) {
+#pragma unroll
+          for (int q = 0; q < NS; ++q) a[q] += v[j][q];
+        }
+      }
     }
   }
 #pragma unroll
   for (int q = 0; q < NS; ++q) sa[q][threadIdx.x] = a[q];
   __syncthreads();
+  // the 64 lane sums of a column are added in lane order, one thread row per quantity (was: all NS chains in one thread)
+  __shared__ float fin[NS][16];
+  if (ty < (unsigned)NS) {
+    float t = 0.f;
+    for (unsigned l = 0; l < 64; ++l) t += sa[ty][l * 16 + tx];
+    fin[ty][tx] = t;
+  }
+  __syncthreads();
   if (ty != 0 || c >= C) return;
 #pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    float t = 0.f;
-    for (unsigned l = 0; l < 64; ++l) t += sa[q][l * 16 + tx];
-    a[q] = t;
-  }
+  for (int q = 0; q < NS; ++q) a[q] = fin[q][tx];
   sums[(size_t)g * 2 * C + c] = a[0];
   sums[(size_t)g * 2 * C + C + c] = a[1];
   if (dgamma) {
