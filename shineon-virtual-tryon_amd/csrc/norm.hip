@@ -31,6 +31,26 @@ __device__ __forceinline__ Mom mom_merge(Mom a, Mom b) {
   return r;
 }
 
+// mom_merge with its two contractions written out.  hipcc (-ffp-contract=fast) fuses `a.mean + d * q` and `s + d * d * q2` in
+// the rolled loops of this file; in the unrolled batch of stats_final_k it fused only some instances - one ulp in the mean,
+// enough to flip ReLU gates downstream and move gradient tensors between acceptance routes.  Written out, the batch
+// reproduces the rolled loop bit for bit (checked on MI355X against the previous build on eight shapes).
+__device__ __forceinline__ Mom mom_merge_fma(Mom a, Mom b) {
+#pragma clang fp contract(off)
+  if (b.n == 0.f) return a;
+  if (a.n == 0.f) return b;
+  Mom r;
+  r.n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float q = b.n / r.n;
+  const float q2 = a.n * b.n / r.n;
+  const float dd = d * d;
+  const float s = a.m2 + b.m2;
+  r.mean = __builtin_fmaf(d, q, a.mean);
+  r.m2 = __builtin_fmaf(dd, q2, s);
+  return r;
+}
+
 constexpr int EPT = 8;   // rows per thread per chunk (at least)
 
 // part layout: [G][nchunk][3][C]
@@ -106,7 +126,7 @@ __global__ __launch_bounds__(1024) void stats_final_k(const float* __restrict__ 
         p2[j] = o[2 * C + c];
       }
 #pragma unroll
-      for (int j = 0; j < FB; ++j) acc = mom_merge(acc, Mom{pn[j], pm[j], p2[j]});   // n == 0: identity
+      for (int j = 0; j < FB; ++j) acc = mom_merge_fma(acc, Mom{pn[j], pm[j], p2[j]});   // n == 0: identity
     }
   }
   sn[threadIdx.x] = acc.n; sm[threadIdx.x] = acc.mean; s2[threadIdx.x] = acc.m2;
