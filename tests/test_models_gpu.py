@@ -269,12 +269,14 @@ def test_attention_head_dim_not_multiple_of_4(cuda):
     assert_close(sa.key_conv.bias.grad, pc["a.key_conv.bias"].grad, atol=1e-4, what="attention d=5 dbk")
 
 
-@pytest.mark.parametrize("c,hw", [(64, (4, 3)), (128, (8, 6)), (512, (16, 12)), (96, (5, 7)), (64, (20, 16))])
+@pytest.mark.parametrize("c,hw", [(64, (4, 3)), (128, (8, 6)), (512, (16, 12)), (96, (5, 7)), (64, (20, 16)), (64, (16, 16)), (32, (15, 15)),
+                                  (64, (13, 16))])
 def test_self_attention_fused_qkv_path(cuda, c, hw):
     """With HipAdam's slab layout (q/k/v weights, biases and gradients adjacent) the three projections and their
     gradients run as single GEMMs accumulating into the gradient slab; same numbers as the oracle.  Up to 256 positions
     everything between the projections is the fused core of csrc/attn.hip (the U-Net's 4x3 / 8x6 / 16x12 maps at 512
-    channels, a ragged 5x7 map), beyond that (20x16) the composed engine launches."""
+    channels, a ragged 5x7 map, and the largest instantiations: 256, 225 and 208 positions), beyond that (20x16) the composed
+    engine launches."""
     from oracle.procedural import procedural_state_dict
     from shineon_virtual_tryon_amd import ops
     from shineon_virtual_tryon_amd.networks.attention.sagan import SelfAttention
