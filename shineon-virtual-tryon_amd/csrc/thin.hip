@@ -269,39 +269,30 @@ __global__ __launch_bounds__(256) void thin_expand_k(const ThinExpand p) {
   // weights -> wl[k = tap * 4 + c][n]; wmode 0: w[n][tap][c] (OHWI, C = 4: forward); 1: w[c][tap][n] (OHWI with four output
   // rows, read for the input gradient: k = tap * 4 + ko).  flip: tap -> 8 - tap (gradient taps run backwards).
   // A thread's <= 9 quads (N <= 256) are fetched in ONE batch of 16-byte loads (was a scalar load -> ds_write loop of 18 rounds
-  // per thread): 11.6 -> 10.2 us per launch on a 4 x 16 x 12 map, 34.8 -> 32.0 on 4 x 256 x 192 (profiles/r06_thin4_launches.txt)
-  if ((((uintptr_t)p.w) & 15) == 0) {
-    constexpr int WQ = 9;
-    const int nq = 9 * p.N;
-    f32x4 wq[WQ];
+  // per thread): 11.6 -> 10.2 us per launch on a 4 x 16 x 12 map, 34.8 -> 32.0 on 4 x 256 x 192 (profiles/r06_thin4_launches.txt).
+  // p.w is 16-byte aligned (so_thin_expand checks; both callers in igemm2.hip already require it).
+  constexpr int WQ = 9;
+  const int nq = 9 * p.N;
+  f32x4 wq[WQ];
 #pragma unroll
-    for (int j = 0; j < WQ; ++j) {
-      const int q = tid + 256 * j;
-      wq[j] = q < nq ? *reinterpret_cast<const f32x4*>(p.w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  for (int j = 0; j < WQ; ++j) {
+    const int q = tid + 256 * j;
+    wq[j] = q < nq ? *reinterpret_cast<const f32x4*>(p.w + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
-    for (int j = 0; j < WQ; ++j) {
-      const int q = tid + 256 * j;
-      if (q >= nq) continue;
-      if (p.wmode == 0) {   // quad = the four channels of one (n, tap)
-        const int n = q / 9, tap = q - n * 9;
-        const int kk = (p.flip ? 8 - tap : tap) << 2;
+  for (int j = 0; j < WQ; ++j) {
+    const int q = tid + 256 * j;
+    if (q >= nq) continue;
+    if (p.wmode == 0) {   // quad = the four channels of one (n, tap)
+      const int n = q / 9, tap = q - n * 9;
+      const int kk = (p.flip ? 8 - tap : tap) << 2;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wl[(kk + c) * NP + n] = wq[j][c];
-      } else {              // quad = four consecutive n of one (c, tap) row
-        const int row = (4 * q) / p.N, n = 4 * q - row * p.N;
-        const int tap = row % 9, c = row / 9;
-        const int kk = ((p.flip ? 8 - tap : tap) << 2) + c;
-        *reinterpret_cast<f32x4*>(wl + kk * NP + n) = wq[j];
-      }
-    }
-  } else {
-    for (int i = tid; i < 36 * p.N; i += 256) {
-      int k, n;
-      if (p.wmode == 0) { n = i / 36; k = i - n * 36; } else { const int row = i / p.N; n = i - row * p.N; k = (row % 9) * 4 + row / 9; }
-      const int tap = k >> 2, c = k & 3;
+      for (int c = 0; c < 4; ++c) wl[(kk + c) * NP + n] = wq[j][c];
+    } else {              // quad = four consecutive n of one (c, tap) row
+      const int row = (4 * q) / p.N, n = 4 * q - row * p.N;
+      const int tap = row % 9, c = row / 9;
       const int kk = ((p.flip ? 8 - tap : tap) << 2) + c;
-      wl[kk * NP + n] = p.w[i];
+      *reinterpret_cast<f32x4*>(wl + kk * NP + n) = wq[j];
     }
   }
   __syncthreads();
@@ -347,7 +338,7 @@ __global__ __launch_bounds__(256) void thin_expand_k(const ThinExpand p) {
 
 int so_thin_expand(int flip, int wmode, const float* in, const float* w, const float* bias, float* y, int ldy, int Nb, int H,
                    int W, int N, int act, float act_param, hipStream_t stream) {
-  if ((N & 63) || N > 256 || (long long)Nb * H * W >= (1 << 30)) return 1;
+  if ((N & 63) || N > 256 || (long long)Nb * H * W >= (1 << 30) || (((uintptr_t)w) & 15)) return 1;
   if (act != SO_ACT_NONE && act != SO_ACT_RELU && act != SO_ACT_LEAKY) return 1;
   ThinExpand p = {};
   p.in = in; p.w = w; p.bias = bias; p.y = y; p.ldy = ldy; p.Nb = Nb; p.H = H; p.W = W; p.N = N; p.flip = flip; p.wmode = wmode;
