@@ -51,6 +51,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
             self._step()
+        self._cache_gen = ops.cache_generation()
 
     def _step(self):
         self.optimizer.zero_grad()
@@ -83,6 +84,7 @@ class GraphedTrainStep:
         _copy_all(dst, src)
 
     def __call__(self, batch=None):
+        _fresh(self)
         if batch is not None:
             self.load_batch(batch)
         self.graph.replay()
@@ -182,6 +184,7 @@ class GraphedChainedStep:
         self.result_tryon = _detached(ru)
         del ru
         self._first = True
+        self._cache_gen = ops.cache_generation()
 
     @staticmethod
     def _load(dst, batch, keys=None):
@@ -199,6 +202,7 @@ class GraphedChainedStep:
     def launch_warp_forward(self, batch=None):
         """side stream: (load the new batch,) warp forward.  Only waits for the previous step's try-on stage to have taken
         its copy of the warped cloth (and, by stream order, for the previous warp backward / Adam)."""
+        _fresh(self)
         if self._first:
             self.side.wait_stream(torch.cuda.current_stream())
             self._first = False
@@ -234,6 +238,15 @@ class GraphedChainedStep:
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+def _fresh(step):
+    """A captured step reads pinned derived copies of frozen weights (Winograd-domain / transposed VGG filters, ops._serve_cached).
+    After ops.invalidate_weight_caches() - load_state_dict, broadcast_parameters: weights overwritten in place - those copies are
+    stale, so the step must be captured again."""
+    if step._cache_gen != ops.cache_generation():
+        raise RuntimeError("parameters were overwritten in place (load_state_dict / broadcast_parameters) after this training step "
+                           "was captured; build a new " + type(step).__name__)
 
 
 def _copy_all(dst, src):

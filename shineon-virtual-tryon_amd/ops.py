@@ -250,24 +250,41 @@ def _ohwi(weight, cpad=None):
 
 
 _IHWO_CACHE = {}
+_CAPTURE_PINS = {}          # data_ptr -> derived-weight copy a captured graph reads through its raw pointer: never freed
+_CACHE_GENERATION = [0]     # bumped by invalidate_weight_caches(); graphs.py refuses to replay a step captured before the bump
+
+
+def _serve_cached(*tensors):
+    """Hand a cache hit to the caller.  Under a stream capture the copy is pinned for the life of the process: the graph keeps
+    only its address, and invalidate_weight_caches() must not free memory a captured step still reads."""
+    if torch.cuda.is_current_stream_capturing():
+        for t in tensors:
+            _CAPTURE_PINS.setdefault(t.data_ptr(), t)
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def cache_generation():
+    return _CACHE_GENERATION[0]
 
 
 def _ihwo(w_ohwi, owner=None):
     """(O, R, S, C) dense OHWI weights -> (C, R, S, O) transposed copy for the KC x KC input-gradient GEMM.
     owner (for frozen weights): (weakref to the owning parameter, its _version at forward time); the copy is
     cached per parameter OBJECT and version, never per address (addresses are recycled between models)."""
-    if owner is not None and torch.cuda.is_current_stream_capturing():
-        owner = None   # a transform recorded into a graph has not RUN yet: never publish it to (or serve) eager callers
+    # Under a stream capture an entry is never CREATED (its transform would be recorded, not run - an eager caller could read it
+    # before the first replay), but entries made by earlier eager launches are served and pinned (_serve_cached): the warm-up
+    # passes in front of a capture fill the caches, so the frozen VGG's derived weights cost a replayed step nothing.
+    capturing = torch.cuda.is_current_stream_capturing()
     if owner is not None:
         ref, version = owner
         p = ref()
         hit = _IHWO_CACHE.get(id(p)) if p is not None else None
         if hit is not None and hit[0]() is p and hit[1] == (version, p.data_ptr()) and hit[2].shape[0] == w_ohwi.shape[3]:
-            return hit[2]
+            return _serve_cached(hit[2])
     o, r, s, c = w_ohwi.shape
     wt = torch.empty((c, r, s, o), dtype=torch.float32, device=w_ohwi.device)
     check(lib().so_ohwi_to_ihwo(w_ohwi.data_ptr(), wt.data_ptr(), o, r * s, c, _stream()), "ohwi_to_ihwo")
-    if owner is not None and owner[0]() is not None:
+    if owner is not None and owner[0]() is not None and not capturing:
         dead = [k for k, v in _IHWO_CACHE.items() if v[0]() is None]
         for k in dead:
             del _IHWO_CACHE[k]
@@ -1038,13 +1055,13 @@ def _stacked_qkv(wq, bq, wk, bk, wv, bv):
         return wq, bq
     if any(t.untyped_storage().nbytes() != t.numel() * 4 for t in ws_ + bs_):
         return None
-    if torch.cuda.is_current_stream_capturing():
-        return None    # no cache traffic under capture (the stacked copy would be recorded, not run): the three-GEMM path
     key = tuple(id(t) for t in ws_ + bs_)
     ver = tuple((t._version, t.data_ptr()) for t in ws_ + bs_)
     hit = _QKV_CACHE.get(key)
     if hit is not None and all(r() is t for r, t in zip(hit[0], ws_ + bs_)) and hit[1] == ver:
-        return hit[2], hit[3]
+        return _serve_cached(hit[2], hit[3])
+    if torch.cuda.is_current_stream_capturing():
+        return None    # no entry is created under capture (the stacked copy would be recorded, not run): the three-GEMM path
     c = wq.shape[1]
     with torch.no_grad():
         wcat = torch.cat([_ohwi(t).reshape(t.shape[0], c) for t in ws_], 0).contiguous()
@@ -1691,13 +1708,13 @@ def _sb16_weights(wk, owner, transpose):
     flipped taps.  Cached per parameter object and version like the transposed fp32 copies."""
     ref, version = owner
     p = ref()
-    if torch.cuda.is_current_stream_capturing():
-        p = None       # see _ihwo: no cache traffic under capture
     version = (version, p.data_ptr()) if p is not None else version
     key = (id(p), bool(transpose))
     hit = _SB16_W_CACHE.get(key) if p is not None else None
     if hit is not None and hit[0]() is p and hit[1] == version:
-        return hit[2], hit[3]
+        return _serve_cached(hit[2], hit[3])
+    if torch.cuda.is_current_stream_capturing():
+        p = None       # see _ihwo: no entry is created under capture
     ko, _, _, c = wk.shape
     hi = torch.empty(ko * 9 * c, dtype=torch.bfloat16, device=wk.device)
     mid = torch.empty_like(hi)
@@ -1715,9 +1732,11 @@ def invalidate_weight_caches():
     """Drop every derived-weight cache (Winograd-domain / transposed / split-bf16 / stacked q-k-v copies of parameters that no
     gradient is asked of).  The caches follow `Tensor._version` and `data_ptr()`; a write that changes neither - `p.data.copy_`,
     `dist.broadcast(p.data)`, the reference-style `m.weight.data.normal_()` - needs this call (trainer.broadcast_parameters
-    and BaseModel.load_state_dict make it)."""
+    and BaseModel.load_state_dict make it).  A graphed step captured before the call reads pinned copies of the old weights and
+    must be rebuilt (its replay raises)."""
     for c in (_WINO_W_CACHE, _IHWO_CACHE, _SB16_W_CACHE, _QKV_CACHE):
         c.clear()
+    _CACHE_GENERATION[0] += 1   # steps captured earlier may hold pinned copies of the OLD weights: graphs.py refuses to replay them
 
 
 def _wino_mode(ci, co, n, h, w):
@@ -1749,8 +1768,6 @@ def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None, f44=False):
     L = lib()
     key = None
     numel = L.so_wino_fused_weight_floats(ko, c, int(transpose)) if fused else (36 if f44 else 16) * ko * c
-    if owner is not None and torch.cuda.is_current_stream_capturing():
-        owner = None   # see _ihwo: a transform recorded into a graph has not run yet - no cache traffic under capture
     if owner is not None:
         ref, version = owner
         p = ref()
@@ -1758,7 +1775,9 @@ def _wino_weights(wk, owner, transpose, fused=False, ko_pad=None, f44=False):
         key = (id(p), bool(transpose), bool(fused), bool(f44))
         hit = _WINO_W_CACHE.get(key) if p is not None else None
         if hit is not None and hit[0]() is p and hit[1] == owner[1] and hit[2].numel() == numel:
-            return hit[2]
+            return _serve_cached(hit[2])
+        if torch.cuda.is_current_stream_capturing():
+            key = None   # see _ihwo: no entry is created under capture
     u = torch.empty(numel, dtype=torch.float32, device=wk.device)
     fn = L.so_wino_fused_weights if fused else (L.so_wino4_weights if f44 else L.so_wino_weights)
     check(fn(wk.data_ptr(), u.data_ptr(), ko, kw, c, int(transpose), _stream()), "wino_weights")

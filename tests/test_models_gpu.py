@@ -778,3 +778,43 @@ def test_bucketed_exchange_overlapped_with_backward_is_bit_identical(cuda, which
         if a is o1._flat[1]:
             continue   # the gradient slab itself: identical too, but it is scratch
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_graphed_step_reads_cached_vgg_filters_and_refuses_a_stale_replay(cuda):
+    """The replayed try-on step must not re-derive the FROZEN VGG19's Winograd-domain / transposed filters: the eager warm-up
+    passes in front of the capture fill ops' derived-weight caches, the capture is served those copies (pinned for the graph,
+    ops._CAPTURE_PINS), and no weight-transform launch is recorded - counted here with the launch counter of the transform
+    entry points.  After ops.invalidate_weight_caches() (weights overwritten in place) the captured step refuses to replay."""
+    from shineon_virtual_tryon_amd import ops
+    from shineon_virtual_tryon_amd.data import synthetic_batch
+    from shineon_virtual_tryon_amd.graphs import GraphedTrainStep
+    from shineon_virtual_tryon_amd.unet_mask_model import UnetMaskModel
+
+    torch.manual_seed(5)
+    model = UnetMaskModel(make_namespace(allow_random_vgg=True, lr=1e-3)).to(cuda).train()
+    model.global_step = 1
+    (opt,), _ = model.configure_optimizers()
+    batch = synthetic_batch(2, cuda, smooth=True)
+    pins0 = set(ops._CAPTURE_PINS)
+    calls = {"n": 0}
+    real = ops._wino_weights
+
+    def counting(wk, owner, *a, **k):
+        capturing = torch.cuda.is_current_stream_capturing()
+        u = real(wk, owner, *a, **k)
+        if capturing and owner is not None and u.data_ptr() not in ops._CAPTURE_PINS:
+            calls["n"] += 1          # a frozen layer's filters were transformed inside the capture
+        return u
+
+    ops._wino_weights = counting
+    try:
+        step = GraphedTrainStep(model, opt, batch)
+    finally:
+        ops._wino_weights = real
+    assert calls["n"] == 0, f"{calls['n']} frozen-weight transforms were recorded into the training graph"
+    assert len(set(ops._CAPTURE_PINS) - pins0) >= 16, "the capture was not served the cached VGG filters"
+    r1 = float(step(batch).minimize)
+    assert np.isfinite(r1)
+    ops.invalidate_weight_caches()
+    with pytest.raises(RuntimeError, match="captured"):
+        step(batch)

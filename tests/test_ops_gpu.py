@@ -419,7 +419,8 @@ def test_self_attention(ops, cuda, hw):
 def test_forward_only_weight_caches_follow_the_parameters(ops, cuda):
     """The gradient-free conv2d path caches the Winograd-domain weights of a stand-alone parameter per (object, version,
     address): an optimizer step (version bump) must be seen, a write through `.data` (no bump) needs
-    ops.invalidate_weight_caches(), and nothing may be cached or served while a stream captures."""
+    ops.invalidate_weight_caches(); while a stream captures no entry is created, entries made by eager launches are served and
+    pinned for the graph (the frozen VGG's Winograd-domain filters inside the replayed training step)."""
     x = rnd(4, 128, 32, 24, seed=90).to(cuda)      # 3072 pixels x 128 channels: the non-fused Winograd form (ops._wino_mode)
     w = torch.nn.Parameter(rnd(128, 128, 3, 3, seed=91, scale=0.05).to(cuda))
     b = torch.nn.Parameter(rnd(128, seed=92, scale=0.1).to(cuda))
@@ -446,7 +447,7 @@ def test_forward_only_weight_caches_follow_the_parameters(ops, cuda):
     y2 = fresh()
     assert not torch.equal(y2, y1)
     assert torch.equal(stale, y1), "expected the documented stale hit without invalidate_weight_caches()"
-    # under capture: neither populated nor served
+    # under capture no entry is CREATED (its transform would be recorded, not run) ...
     ops.invalidate_weight_caches()
     g = torch.cuda.CUDAGraph()
     with torch.no_grad(), torch.cuda.graph(g):
@@ -455,6 +456,23 @@ def test_forward_only_weight_caches_follow_the_parameters(ops, cuda):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(ops.to_nchw(yc), y2)
+    # ... but an entry made by an eager launch is served to a capture, and pinned: the graph must survive the cache being dropped
+    with torch.no_grad():
+        ops.conv2d(x, w, b, 1, 1)
+    torch.cuda.synchronize()
+    (entry,) = list(ops._WINO_W_CACHE.values())
+    pins = len(ops._CAPTURE_PINS)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g2):
+        yc2 = ops.conv2d(x, w, b, 1, 1)
+    assert entry[2].data_ptr() in ops._CAPTURE_PINS and len(ops._CAPTURE_PINS) == pins + 1
+    gen = ops.cache_generation()
+    ops.invalidate_weight_caches()
+    assert ops.cache_generation() == gen + 1
+    torch.empty(entry[2].numel(), device=cuda).fill_(float("nan"))     # would land in the freed copy if it had been freed
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ops.to_nchw(yc2), y2)
 
 
 def test_winograd_fused_block_orders_are_bit_identical(ops, cuda):
