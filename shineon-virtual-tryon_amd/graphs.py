@@ -49,7 +49,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
+        self._pins = []   # derived-weight copies the graph reads through raw pointers (ops._serve_cached)
+        with ops.capture_pins(self._pins), torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
             self._step()
         self._cache_gen = ops.cache_generation()
 
@@ -173,7 +174,8 @@ class GraphedChainedStep:
         self.cloth_tryon.copy_(self.warped)
         b2 = dict(self.batch_tryon)
         b2["cloth"] = self.cloth_tryon
-        with torch.cuda.graph(self.g_u, capture_error_mode=capture_mode()):
+        self._pins = []   # derived-weight copies (frozen VGG filters) the try-on graph reads through raw pointers
+        with ops.capture_pins(self._pins), torch.cuda.graph(self.g_u, capture_error_mode=capture_mode()):
             optu.zero_grad()
             if exu is not None:
                 exu.begin()

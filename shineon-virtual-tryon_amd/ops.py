@@ -250,17 +250,38 @@ def _ohwi(weight, cpad=None):
 
 
 _IHWO_CACHE = {}
-_CAPTURE_PINS = {}          # data_ptr -> derived-weight copy a captured graph reads through its raw pointer: never freed
+_CAPTURE_PINS = {}          # data_ptr -> derived-weight copy read by a graph captured outside graphs.py: never freed
+_PIN_SINK = [None]          # graphs.py: the list of the step being captured - its pins live exactly as long as the step
 _CACHE_GENERATION = [0]     # bumped by invalidate_weight_caches(); graphs.py refuses to replay a step captured before the bump
 
 
 def _serve_cached(*tensors):
-    """Hand a cache hit to the caller.  Under a stream capture the copy is pinned for the life of the process: the graph keeps
-    only its address, and invalidate_weight_caches() must not free memory a captured step still reads."""
+    """Hand a cache hit to the caller.  Under a stream capture the copy is pinned: the graph keeps only its address, and
+    invalidate_weight_caches() must not free memory a captured step still reads.  The pin belongs to the step being captured
+    (capture_pins) or, for a bare torch.cuda.graph, to the process."""
     if torch.cuda.is_current_stream_capturing():
+        sink = _PIN_SINK[0]
         for t in tensors:
-            _CAPTURE_PINS.setdefault(t.data_ptr(), t)
+            if sink is not None:
+                sink.append(t)
+            else:
+                _CAPTURE_PINS.setdefault(t.data_ptr(), t)
     return tensors[0] if len(tensors) == 1 else tensors
+
+
+class capture_pins:
+    """with ops.capture_pins(step_pins): ...capture...  - cache copies served during the capture are appended to `step_pins`."""
+
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        self.prev, _PIN_SINK[0] = _PIN_SINK[0], self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        _PIN_SINK[0] = self.prev
+        return False
 
 
 def cache_generation():

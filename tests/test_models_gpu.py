@@ -782,8 +782,8 @@ def test_bucketed_exchange_overlapped_with_backward_is_bit_identical(cuda, which
 
 def test_graphed_step_reads_cached_vgg_filters_and_refuses_a_stale_replay(cuda):
     """The replayed try-on step must not re-derive the FROZEN VGG19's Winograd-domain / transposed filters: the eager warm-up
-    passes in front of the capture fill ops' derived-weight caches, the capture is served those copies (pinned for the graph,
-    ops._CAPTURE_PINS), and no weight-transform launch is recorded - counted here with the launch counter of the transform
+    passes in front of the capture fill ops' derived-weight caches, the capture is served those copies (pinned by the step,
+    GraphedTrainStep._pins), and no weight-transform launch is recorded - counted here with the launch counter of the transform
     entry points.  After ops.invalidate_weight_caches() (weights overwritten in place) the captured step refuses to replay."""
     from shineon_virtual_tryon_amd import ops
     from shineon_virtual_tryon_amd.data import synthetic_batch
@@ -795,14 +795,13 @@ def test_graphed_step_reads_cached_vgg_filters_and_refuses_a_stale_replay(cuda):
     model.global_step = 1
     (opt,), _ = model.configure_optimizers()
     batch = synthetic_batch(2, cuda, smooth=True)
-    pins0 = set(ops._CAPTURE_PINS)
     calls = {"n": 0}
     real = ops._wino_weights
 
     def counting(wk, owner, *a, **k):
         capturing = torch.cuda.is_current_stream_capturing()
         u = real(wk, owner, *a, **k)
-        if capturing and owner is not None and u.data_ptr() not in ops._CAPTURE_PINS:
+        if capturing and owner is not None and not any(u is t for t in ops._PIN_SINK[0]):
             calls["n"] += 1          # a frozen layer's filters were transformed inside the capture
         return u
 
@@ -812,7 +811,7 @@ def test_graphed_step_reads_cached_vgg_filters_and_refuses_a_stale_replay(cuda):
     finally:
         ops._wino_weights = real
     assert calls["n"] == 0, f"{calls['n']} frozen-weight transforms were recorded into the training graph"
-    assert len(set(ops._CAPTURE_PINS) - pins0) >= 16, "the capture was not served the cached VGG filters"
+    assert len({t.data_ptr() for t in step._pins}) >= 16, "the capture was not served the cached VGG filters"
     r1 = float(step(batch).minimize)
     assert np.isfinite(r1)
     ops.invalidate_weight_caches()
